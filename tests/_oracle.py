@@ -1,0 +1,231 @@
+"""ctypes front-ends for the TEST-ONLY checkers under oracle/.
+
+* ``Oracle``    - oracle/librrt_oracle.so, the CPU restatement (oracle/rrt_oracle.cpp).
+* ``Reference`` - oracle/_ref/libref_f32.so / libref_f64.so, the reference's own sources compiled
+  unchanged with the product's RNG hooked in (oracle/ref_harness.cpp).  Exists only where
+  oracle/_ref was built (this container; it travels to the GPU box as a prebuilt file).
+
+Nothing in the product (rrt_amd/, include/) imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "librrt_oracle.so")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name if name.endswith(".txt") else name + ".txt")
+
+
+def build_oracle():
+    """(Re)build oracle/librrt_oracle.so when missing or stale (CPU only, ~5 s)."""
+    src = os.path.join(ORACLE_DIR, "rrt_oracle.cpp")
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "librrt_oracle.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def have_reference():
+    return os.path.exists(os.path.join(REF_DIR, "libref_f32.so")) and os.path.exists(os.path.join(REF_DIR, "libref_f64.so"))
+
+
+def _np(fp64):
+    return np.float64 if fp64 else np.float32
+
+
+class _Tables:
+    """cam24 / materials(n,6) / spheres(n,5) / msph(n,10) / tris(n,10) as float64 arrays."""
+
+    def __init__(self, counts, dump):
+        nm, ns, nms, nt = counts[0], counts[1], counts[2], counts[3]
+        self.counts = list(counts)
+        self.cam = np.zeros(24)
+        self.materials = np.zeros((nm, 6))
+        self.spheres = np.zeros((ns, 5))
+        self.msph = np.zeros((nms, 10))
+        self.tris = np.zeros((nt, 10))
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        dump(p(self.cam), p(self.materials), p(self.spheres), p(self.msph), p(self.tris))
+
+
+class Oracle:
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = C.CDLL(build_oracle())
+            L.rrto_scene_load.restype = C.c_void_p
+            L.rrto_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+            L.rrto_scene_free.argtypes = [C.c_void_p]
+            L.rrto_scene_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            L.rrto_scene_dump.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 5
+            L.rrto_render.restype = C.c_int
+            L.rrto_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+            L.rrto_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+            L.rrto_quantise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.rrto_convert_color.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int)]
+            L.rrto_rng_words.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
+            L.rrto_rng_f32.restype = C.c_float
+            L.rrto_rng_f32.argtypes = [C.c_uint32] * 4
+            L.rrto_rng_f64.restype = C.c_double
+            L.rrto_rng_f64.argtypes = [C.c_uint32] * 4
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, scene_file, w, h, fp64=False):
+        L = self.lib()
+        err = C.c_int(0)
+        self.fp64 = bool(fp64)
+        self.w, self.h = w, h
+        self.h_ = L.rrto_scene_load(scene_file.encode(), w, h, int(fp64), C.byref(err))
+        self.err = err.value
+        if not self.h_:
+            raise ValueError("oracle: scene load failed with reference exit code %d" % self.err)
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            self.lib().rrto_scene_free(self.h_)
+            self.h_ = None
+
+    def counts(self):
+        c = (C.c_int * 6)()
+        self.lib().rrto_scene_counts(self.h_, c)
+        return list(c)
+
+    def tables(self):
+        return _Tables(self.counts(), lambda *a: self.lib().rrto_scene_dump(self.h_, *a))
+
+    def render(self, spp, depth=50, seed=1984, order=1, chunk=0, rows=None):
+        """-> (fb[h,w,3] row 0 = bottom, stats dict). order 0 = recursive (rrt.cpp), 1 = iterative (rrt.cu)."""
+        fb = np.zeros((self.h, self.w, 3), dtype=_np(self.fp64))
+        st = (C.c_uint64 * 4)()
+        r0, r1 = rows if rows else (0, self.h)
+        rc = self.lib().rrto_render(self.h_, self.w, self.h, spp, depth, seed, order, chunk, r0, r1, fb.ctypes.data_as(C.c_void_p), st)
+        assert rc == 0
+        return fb, dict(segments=st[0], prim_tests=st[1], draws=st[2], samples=st[3])
+
+    def sample(self, i, j, s, depth=50, seed=1984, order=1):
+        out = (C.c_double * 3)()
+        st = (C.c_uint64 * 4)()
+        self.lib().rrto_sample(self.h_, self.w, self.h, i, j, s, depth, seed, order, out, st)
+        return np.array(list(out)), dict(segments=st[0], prim_tests=st[1], draws=st[2])
+
+    @classmethod
+    def quantise(cls, fb, spp):
+        fp64 = fb.dtype == np.float64
+        h, w, _ = fb.shape
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        fbc = np.ascontiguousarray(fb)
+        cls.lib().rrto_quantise(fbc.ctypes.data_as(C.c_void_p), int(fp64), w, h, spp, rgb.ctypes.data_as(C.c_void_p))
+        return rgb
+
+    @classmethod
+    def convert_color(cls, rgb, spp, fp64=False):
+        a = (C.c_double * 3)(*[float(x) for x in rgb])
+        o = (C.c_int * 3)()
+        cls.lib().rrto_convert_color(a, int(fp64), spp, o)
+        return list(o)
+
+    @classmethod
+    def rng_words(cls, seed, pixel, sample, n):
+        o = (C.c_uint32 * 4)()
+        cls.lib().rrto_rng_words(seed, pixel, sample, n, o)
+        return list(o)  # k0, k1, hi, lo
+
+    @classmethod
+    def rng_uniform(cls, seed, pixel, sample, n, fp64=False):
+        L = cls.lib()
+        return L.rrto_rng_f64(seed, pixel, sample, n) if fp64 else L.rrto_rng_f32(seed, pixel, sample, n)
+
+
+class Reference:
+    """The reference's own code (compiled into oracle/_ref by `make -C oracle ref`)."""
+
+    _libs = {}
+
+    @classmethod
+    def lib(cls, fp64):
+        key = bool(fp64)
+        if key not in cls._libs:
+            L = C.CDLL(os.path.join(REF_DIR, "libref_f64.so" if fp64 else "libref_f32.so"))
+            L.ref_scene_load.restype = C.c_void_p
+            L.ref_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int]
+            L.ref_scene_free.argtypes = [C.c_void_p]
+            L.ref_scene_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            L.ref_sizeof.restype = C.c_int
+            L.ref_sizeof.argtypes = [C.c_int]
+            L.ref_scene_raw.argtypes = [C.c_void_p] * 6
+            L.ref_scene_dump.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 5
+            L.ref_render.restype = C.c_int
+            L.ref_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.ref_quantise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+            L.ref_convert_color.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+            L.ref_ppm.restype = C.c_int
+            L.ref_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+            L.ref_rng_probe.restype = C.c_double
+            L.ref_rng_probe.argtypes = [C.c_uint32] * 4
+            cls._libs[key] = L
+        return cls._libs[key]
+
+    def __init__(self, scene_file, w, h, fp64=False):
+        self.fp64 = bool(fp64)
+        self.L = self.lib(fp64)
+        self.w, self.h = w, h
+        self.h_ = self.L.ref_scene_load(scene_file.encode(), w, h)
+
+    def counts(self):
+        c = (C.c_int * 6)()
+        self.L.ref_scene_counts(self.h_, c)
+        return list(c)
+
+    def sizeof(self):
+        return [self.L.ref_sizeof(k) for k in range(6)]
+
+    def tables(self):
+        return _Tables(self.counts(), lambda *a: self.L.ref_scene_dump(self.h_, *a))
+
+    def raw(self):
+        """Raw bytes of the reference's POD tables (what rrt.cu:217-247 marshals)."""
+        cnt = self.counts()
+        sz = self.sizeof()
+        bufs = [np.zeros(sz[1], np.uint8), np.zeros(cnt[0] * sz[2], np.uint8), np.zeros(cnt[1] * sz[3], np.uint8), np.zeros(cnt[2] * sz[4], np.uint8),
+                np.zeros(cnt[3] * sz[5], np.uint8)]
+        self.L.ref_scene_raw(self.h_, *[b.ctypes.data_as(C.c_void_p) if b.size else None for b in bufs])
+        return bufs
+
+    def render(self, spp, depth=50, seed=1984, bvh=False, rows=None):
+        fb = np.zeros((self.h, self.w, 3), dtype=_np(self.fp64))
+        r0, r1 = rows if rows else (0, self.h)
+        rc = self.L.ref_render(self.h_, self.w, self.h, spp, depth, seed, int(bvh), r0, r1, fb.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return fb
+
+    def quantise(self, fb, spp):
+        h, w, _ = fb.shape
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        fbc = np.ascontiguousarray(fb, dtype=_np(self.fp64))
+        self.L.ref_quantise(fbc.ctypes.data_as(C.c_void_p), w, h, spp, rgb.ctypes.data_as(C.c_void_p))
+        return rgb
+
+    def convert_color(self, rgb, spp):
+        a = (C.c_double * 3)(*[float(x) for x in rgb])
+        o = (C.c_int * 3)()
+        self.L.ref_convert_color(a, spp, o)
+        return list(o)
+
+    def ppm(self, fb, spp, path):
+        h, w, _ = fb.shape
+        fbc = np.ascontiguousarray(fb, dtype=_np(self.fp64))
+        assert self.L.ref_ppm(fbc.ctypes.data_as(C.c_void_p), w, h, spp, path.encode()) == 0
+
+    def rng_probe(self, seed, pixel, sample, n):
+        return self.L.ref_rng_probe(seed, pixel, sample, n)
