@@ -1,0 +1,219 @@
+/*
+ * rrtx.h — C ABI of the MI355X-native render path for rogerallen/rrt.
+ *
+ * This is the drop-in boundary for the reference's ONE hot path: everything `Rrt::render`
+ * does on the device (rrt.cu:186-334) and, on the host side of it, the three things its only
+ * caller needs (main.cpp:123-167): a scene parsed into POD tables, the framebuffer, and the
+ * 8-bit quantiser / image writers.  Plain pointers and sizes only — no C++ types, no torch
+ * types, no exceptions cross this boundary; every entry point returns 0 or a negative
+ * RRTX_E_* code (host callers map non-zero to "print + exit(99)", the behaviour of
+ * check_cuda, rrt.cu:31-40).  All file:line citations are into the reference repository.
+ *
+ * The table structs below are LAYOUT-IDENTICAL to what the reference marshals to its
+ * create_world kernel (rrt.cu:124-128, 217-247): scene.h:27-54 (triangle / sphere / moving
+ * sphere), scene.h:183-208 (material) and camera.h:43-48 (camera), in both FP_T = float
+ * (`rrt`) and FP_T = double (`rrtd`) builds.  A reference maintainer can therefore hand the
+ * arrays rrt.cu already builds straight to rrtx_set_scene().
+ */
+#ifndef RRTX_H
+#define RRTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTX_VERSION_STRING "rrtx 0.1 (gfx950)"
+
+/* ---- error codes ------------------------------------------------------------------- */
+#define RRTX_OK 0
+#define RRTX_E_INVALID (-1)   /* bad argument / inconsistent parameters                    */
+#define RRTX_E_DEVICE (-2)    /* HIP runtime error (message in rrtx_last_error())          */
+#define RRTX_E_NO_SCENE (-3)  /* render called before rrtx_set_scene                       */
+#define RRTX_E_IO (-4)        /* file could not be opened / written                        */
+#define RRTX_E_PARSE (-5)     /* scene file rejected; rrtx_scene_exit_code() has the
+                                 reference's exit code (1..4)                              */
+#define RRTX_E_UNSUPPORTED (-6)
+
+/* ---- POD tables (reference layouts) ------------------------------------------------ */
+enum { RRTX_LAMBERTIAN = 0, RRTX_METAL = 1, RRTX_DIELECTRIC = 2 }; /* scene.h:181 */
+
+/* camera.h:43-48: origin, lower_left_corner, horizontal, vertical, u, v, w, lens_radius,
+ * time0, time1 — 24 FP_T, 96 B (float) / 192 B (double). */
+typedef struct rrtx_camera_f32 {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius, time0, time1;
+} rrtx_camera_f32;
+typedef struct rrtx_camera_f64 {
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    double lens_radius, time0, time1;
+} rrtx_camera_f64;
+
+/* scene.h:183-208: enum type @0, union @8; 32 B (float) / 40 B (double). */
+typedef struct rrtx_material_f32 {
+    int32_t type;
+    union {
+        struct { float albedo[3]; } lambertian;
+        struct { float albedo[3]; double fuzz; } metal;
+        struct { double ref_idx; } dielectric;
+    } mat;
+} rrtx_material_f32;
+typedef struct rrtx_material_f64 {
+    int32_t type;
+    union {
+        struct { double albedo[3]; } lambertian;
+        struct { double albedo[3]; double fuzz; } metal;
+        struct { double ref_idx; } dielectric;
+    } mat;
+} rrtx_material_f64;
+
+/* scene.h:43-47: 32 B (float; radius @16, material_idx @24) / 40 B (double). */
+typedef struct rrtx_sphere_f32 { float center[3]; double radius; int32_t material_idx; } rrtx_sphere_f32;
+typedef struct rrtx_sphere_f64 { double center[3]; double radius; int32_t material_idx; } rrtx_sphere_f64;
+
+/* scene.h:49-54: 56 B (float) / 80 B (double). */
+typedef struct rrtx_moving_sphere_f32 { float center0[3], center1[3]; double time0, time1, radius; int32_t material_idx; } rrtx_moving_sphere_f32;
+typedef struct rrtx_moving_sphere_f64 { double center0[3], center1[3]; double time0, time1, radius; int32_t material_idx; } rrtx_moving_sphere_f64;
+
+/* scene.h:27-41 scene_instance_triangle (post-transform, flattened): 40 B / 80 B. */
+typedef struct rrtx_triangle_f32 { float vertices[3][3]; int32_t material_idx; } rrtx_triangle_f32;
+typedef struct rrtx_triangle_f64 { double vertices[3][3]; int32_t material_idx; } rrtx_triangle_f64;
+
+/* What crosses to the device — the argument list of create_world (rrt.cu:124-128).  All
+ * pointers are caller-owned host memory, read during rrtx_set_scene() only. */
+typedef struct rrtx_scene_desc {
+    int32_t fp64;               /* 0: the *_f32 structs above, 1: the *_f64 ones            */
+    const void *camera;
+    int32_t num_materials;
+    const void *materials;
+    int32_t num_spheres;
+    const void *spheres;
+    int32_t num_moving_spheres;
+    const void *moving_spheres;
+    int32_t num_triangles;
+    const void *triangles;
+} rrtx_scene_desc;
+
+/* ---- render context ------------------------------------------------------------------ */
+/* Constructor arguments of class Rrt (rrt.h:16-31) plus what the MI355X path adds. */
+typedef struct rrtx_params {
+    int32_t image_width, image_height; /* -w / -h                                          */
+    int32_t samples_per_pixel;         /* -s                                               */
+    int32_t max_depth;                 /* -d                                               */
+    int32_t use_bvh;                   /* -b clears it.  Accepted for drop-in; this path is
+                                          the brute-force hittable_list scan either way.    */
+    int32_t threads_x, threads_y;      /* -tx / -ty: accepted; reported in the stats line    */
+    int32_t fp64;                      /* 0 = `rrt` (float), 1 = `rrtd` (double)            */
+    int32_t device;                    /* HIP device ordinal (-D)                           */
+    uint32_t seed;                     /* RNG base seed; 0 selects 1984 (cf. rrt.cu:88)     */
+    int32_t sample_chunk;              /* samples per work item; 0 = automatic, >= spp (or
+                                          -1) = one item per pixel = the reference's own
+                                          summation order                                   */
+    /* Row-tile sharding of the frame over `shard_count` devices/processes: rows are cut into
+     * tiles of `tile_rows`, tile t belongs to shard (t mod shard_count).  count 0/1 = whole
+     * frame.  The image is bit-identical for every (shard_count, tile_rows).               */
+    int32_t shard_rank, shard_count, tile_rows;
+    int32_t collect_stats;             /* 1: count segments / primitive tests on the device  */
+    int32_t reserved[3];
+} rrtx_params;
+
+typedef struct rrtx_stats {
+    double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
+                                render, measured on the stream they were launched on         */
+    double kernel_ms_sum;    /* the same, summed over the `renders` launches since the
+                                previous rrtx_collect / rrtx_render                          */
+    int32_t renders;
+    int32_t reserved0;
+    double wall_ms;          /* host wall time of the last blocking render call              */
+    uint64_t samples;        /* pixels_rendered * spp                                        */
+    uint64_t segments;       /* path segments traced (0 unless collect_stats)                */
+    uint64_t prim_tests;     /* primitive intersection tests = segments * num_primitives     */
+    uint64_t bytes_algorithmic; /* prim_tests * B_prim + framebuffer bytes     */
+    int32_t grid_blocks, block_threads;
+    int32_t sample_chunk;    /* the value actually used                                      */
+    int32_t local_rows;      /* rows rendered by this shard                                  */
+} rrtx_stats;
+
+typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */
+    char name[256];
+    int32_t major, minor;
+    int32_t multi_processor_count;
+    int64_t shared_mem_per_block;
+    int32_t max_threads_per_block;
+    int32_t max_threads_per_multiprocessor;
+    int32_t unified_addressing;
+    int32_t l2_cache_size;
+    int64_t total_global_mem;
+    int32_t clock_khz;
+} rrtx_devinfo;
+
+typedef struct rrtx_ctx rrtx_ctx;
+
+const char *rrtx_version(void);
+/* Thread-local description of the last failure on the calling thread ("" if none). */
+const char *rrtx_last_error(void);
+
+int rrtx_device_count(void);                       /* main.cpp:17 cudaGetDeviceCount        */
+int rrtx_query(int device, rrtx_devinfo *out);     /* main.cpp:19 cudaGetDeviceProperties   */
+int rrtx_runtime_version(void);                    /* rrt.cu:195 cudaRuntimeGetVersion      */
+
+/* Rrt::Rrt (rrt.h:16-31). */
+int rrtx_create(const rrtx_params *params, rrtx_ctx **out);
+/* Rrt::~Rrt (rrt.cu:336-342). Safe on NULL. */
+void rrtx_destroy(rrtx_ctx *ctx);
+
+/* The marshalling half of Rrt::render (rrt.cu:217-270): packs the tables into the device
+ * layout and uploads them.  Replaces create_world<<<1,1>>>.  May be called again to swap
+ * scenes on a live context. */
+int rrtx_set_scene(rrtx_ctx *ctx, const rrtx_scene_desc *scene);
+
+/* Rows of the frame this context renders (global row numbers, ascending; row 0 = bottom of
+ * the image, rrt.cu:117).  Returns the count; fills at most `cap` entries when rows != NULL. */
+int rrtx_shard_rows(const rrtx_ctx *ctx, int32_t *rows, int cap);
+
+/* The launch half of Rrt::render (rrt.cu:286-298) + copy-back.  `fb` is caller-owned host
+ * memory of image_width*image_height*3 FP_T (float or double per params.fp64), pixel (i,j) at
+ * (j*image_width+i)*3, row 0 = bottom, un-normalised sum over samples — exactly the buffer
+ * Rrt::render returns (rrt.cu:118).  Only this shard's rows are written.  Blocking. */
+int rrtx_render(rrtx_ctx *ctx, void *fb, rrtx_stats *stats);
+
+/* Same render, output left in device memory: `d_rows` is a device pointer to
+ * rrtx_shard_rows()*image_width*3 FP_T, local row k = k-th row of rrtx_shard_rows().
+ * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous: returns
+ * after enqueueing; the framebuffer is complete when the stream reaches this point.  This is
+ * the entry point the multi-GPU gather and bench.py use (inputs resident in HBM). */
+int rrtx_render_device(rrtx_ctx *ctx, void *d_rows, void *hip_stream);
+
+/* Waits for the renders enqueued so far and fills `stats` for the last one. */
+int rrtx_collect(rrtx_ctx *ctx, rrtx_stats *stats);
+
+/* ---- host side of the seam: scene parser (scene.h:212-452) ----------------------------- */
+typedef struct rrtx_scene rrtx_scene;
+/* Parses `path` for a w x h frame (the camera's aspect ratio comes from them, scene.h:254).
+ * On a rejected file returns RRTX_E_PARSE / RRTX_E_IO and *out = NULL. */
+int rrtx_scene_load(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out);
+/* The reference's process exit code for the last rrtx_scene_load failure on this thread
+ * (scene.h:222,289,433-441: 1 = obj errors, 2 = cannot open, 3 = unknown material, 4 = scene
+ * sanity). */
+int rrtx_scene_exit_code(void);
+void rrtx_scene_free(rrtx_scene *s);
+/* Borrowed view of the parsed tables, valid until rrtx_scene_free. */
+int rrtx_scene_describe(const rrtx_scene *s, rrtx_scene_desc *out);
+/* counts[6]: materials, spheres, moving spheres, instance triangles, objs, obj instances
+ * (the numbers scene.h:443-448 prints). */
+int rrtx_scene_counts(const rrtx_scene *s, int32_t counts[6]);
+
+/* ---- host side of the seam: output (color.h:8-32, main.cpp:140-167) -------------------- */
+/* 8-bit quantiser: fb (row 0 = bottom) -> rgb (top row first), w*h*3 bytes. */
+int rrtx_quantise(const void *fb, int fp64, int image_width, int image_height, int samples_per_pixel, uint8_t *rgb);
+/* ASCII PPM "P3" exactly as main.cpp:142-148 prints it; path NULL or "-" = stdout. */
+int rrtx_write_ppm(const char *path, const uint8_t *rgb, int image_width, int image_height);
+/* 8-bit RGB PNG (decoded pixels identical to the reference's stbi_write_png output). */
+int rrtx_write_png(const char *path, const uint8_t *rgb, int image_width, int image_height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRTX_H */

@@ -1,0 +1,15 @@
+"""rrt_amd - host-side mirror of the rogerallen/rrt render interface over the MI355X-native C ABI.
+
+    scene = rrt_amd.Scene("scenes/final.txt", 1200, 800)          # scene.h:212  scene(filename, w, h)
+    rrt   = rrt_amd.Rrt(1200, 800, 500, 50, use_bvh=False)        # rrt.h:16     Rrt(w, h, spp, depth, bvh[, tx, ty])
+    fb    = rrt.render(scene)                                     # rrt.h:34     vec3* render(scene*)
+    rgb   = rrt_amd.quantise(fb, 500)                             # color.h:8    convert_color, main.cpp:153 row flip
+    rrt_amd.write_png("out.png", rgb)                             # main.cpp:164
+
+Everything computes in librrtx.so (hand-written HIP for gfx950); nothing here falls back to
+Python/CPU arithmetic.
+"""
+from ._lib import RrtxError  # noqa: F401
+from .render import Rrt, Scene, device_count, query_device, quantise, write_png, write_ppm  # noqa: F401
+
+__all__ = ["Rrt", "Scene", "RrtxError", "device_count", "query_device", "quantise", "write_png", "write_ppm"]

@@ -1,0 +1,530 @@
+// C ABI of the render path (include/rrtx.h): context, scene packing/upload, launches, timing.
+// The host half of Rrt::render (rrt.cu:186-334), without the device heap, the 1-thread
+// create_world kernel or the per-pixel curand state.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtx.h"
+#include "rrtx_launch.h"
+
+namespace {
+
+using namespace rrtx;
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define RRTX_HIP(expr)                                                                                                   \
+    do {                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                          \
+        if (e_ != hipSuccess) {                                                                                          \
+            char buf_[512];                                                                                              \
+            snprintf(buf_, sizeof buf_, "HIP error = %u (%s) at %s:%d '%s'", (unsigned)e_, hipGetErrorString(e_), __FILE__, \
+                     __LINE__, #expr);                                                                                   \
+            return fail(RRTX_E_DEVICE, buf_);                                                                            \
+        }                                                                                                                \
+    } while (0)
+
+template <typename F> struct RefTypes;
+template <> struct RefTypes<float> {
+    typedef rrtx_camera_f32 camera;
+    typedef rrtx_material_f32 material;
+    typedef rrtx_sphere_f32 sphere;
+    typedef rrtx_moving_sphere_f32 moving_sphere;
+    typedef rrtx_triangle_f32 triangle;
+};
+template <> struct RefTypes<double> {
+    typedef rrtx_camera_f64 camera;
+    typedef rrtx_material_f64 material;
+    typedef rrtx_sphere_f64 sphere;
+    typedef rrtx_moving_sphere_f64 moving_sphere;
+    typedef rrtx_triangle_f64 triangle;
+};
+
+constexpr int kEventRing = 64;
+
+} // namespace
+
+struct rrtx_ctx {
+    rrtx_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int blocks_per_cu = 0;
+    // derived geometry of this shard
+    int local_rows = 0;
+    int chunk = 0, chunks_per_pixel = 0;
+    uint32_t total_tasks = 0;
+    size_t fsize = 4;
+    // scene
+    bool have_scene = false;
+    int n_sph = 0, n_sph_padded = 0, n_msph = 0, n_tri = 0, n_mat = 0;
+    void *d_hot = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_mat = nullptr;
+    unsigned char cam_bytes[sizeof(CameraRec<double>)];
+    // work buffers
+    uint32_t *d_queue = nullptr;
+    unsigned long long *d_counters = nullptr;
+    void *d_partial = nullptr; // [total_tasks][3] when chunks_per_pixel > 1
+    void *d_rows = nullptr;    // own output buffer for the host-pointer API
+    // timing
+    hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
+    int ev_pending = 0;
+    double kernel_ms_total = 0.0;
+    long renders_total = 0;
+    int grid_blocks = 0;
+    double last_wall_ms = 0.0;
+};
+
+namespace {
+
+int rows_of_shard(const rrtx_params &p, std::vector<int32_t> *out)
+{
+    int count = 0;
+    const int n = p.shard_count < 1 ? 1 : p.shard_count;
+    const int T = p.tile_rows < 1 ? 1 : p.tile_rows;
+    for (int j = 0; j < p.image_height; ++j) {
+        if ((j / T) % n == p.shard_rank) {
+            if (out) out->push_back(j);
+            ++count;
+        }
+    }
+    return count;
+}
+
+template <typename F> void pack_unit(const F v[3], F out[3])
+{
+    // vec3.h:125 unit_vector = (1/len) * v
+    F len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    F inv = (F)1 / len;
+    out[0] = inv * v[0], out[1] = inv * v[1], out[2] = inv * v[2];
+}
+
+template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
+{
+    typedef RefTypes<F> R;
+    const typename R::camera *cam = (const typename R::camera *)s->camera;
+    const typename R::material *mats = (const typename R::material *)s->materials;
+    const typename R::sphere *sph = (const typename R::sphere *)s->spheres;
+    const typename R::moving_sphere *msp = (const typename R::moving_sphere *)s->moving_spheres;
+    const typename R::triangle *tri = (const typename R::triangle *)s->triangles;
+
+    // camera.h:43-48 has the same member order as CameraRec
+    static_assert(sizeof(typename R::camera) == sizeof(CameraRec<F>), "camera layout");
+    memcpy(c->cam_bytes, cam, sizeof(CameraRec<F>));
+
+    // materials: what create_world builds (rrt.cu:137-148; material.h:19,48,74)
+    std::vector<MaterialRec<F>> hmat(s->num_materials > 0 ? s->num_materials : 1);
+    for (int i = 0; i < s->num_materials; ++i) {
+        MaterialRec<F> m = {};
+        m.type = mats[i].type;
+        if (mats[i].type == RRTX_LAMBERTIAN) {
+            m.r = mats[i].mat.lambertian.albedo[0], m.g = mats[i].mat.lambertian.albedo[1], m.b = mats[i].mat.lambertian.albedo[2];
+        }
+        else if (mats[i].type == RRTX_METAL) {
+            m.r = mats[i].mat.metal.albedo[0], m.g = mats[i].mat.metal.albedo[1], m.b = mats[i].mat.metal.albedo[2];
+            F f = (F)mats[i].mat.metal.fuzz;
+            m.param = f < (F)1.0 ? f : (F)1.0;
+        }
+        else if (mats[i].type == RRTX_DIELECTRIC) {
+            m.param = (F)mats[i].mat.dielectric.ref_idx;
+        }
+        else
+            return fail(RRTX_E_INVALID, "rrtx_set_scene: unknown material type");
+        hmat[i] = m;
+    }
+
+    auto check_mat = [&](int idx) { return idx >= 0 && idx < s->num_materials; };
+
+    // spheres: hot {center, r*r} + cold {r, material}; padded with never-hit records
+    const int pad = kSphereUnroll;
+    const int n_pad = ((s->num_spheres + pad - 1) / pad) * pad;
+    std::vector<SphereHot<F>> hhot(n_pad > 0 ? n_pad : 1);
+    std::vector<SphereCold<F>> hcold(n_pad > 0 ? n_pad : 1);
+    for (int i = 0; i < n_pad; ++i) {
+        if (i < s->num_spheres) {
+            if (!check_mat(sph[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: sphere material index out of range");
+            F r = (F)sph[i].radius; // sphere(cen, FP_T r, m), sphere.h:11
+            hhot[i].cx = sph[i].center[0], hhot[i].cy = sph[i].center[1], hhot[i].cz = sph[i].center[2];
+            hhot[i].r2 = r * r; // sphere.h:38
+            hcold[i].radius = r;
+            hcold[i].mat = sph[i].material_idx;
+        }
+        else {
+            // c = |oc|^2 + inf => discriminant = -inf: never a candidate (and phase 2 skips k >= n_sph)
+            hhot[i].cx = hhot[i].cy = hhot[i].cz = 0;
+            hhot[i].r2 = -std::numeric_limits<F>::infinity();
+            hcold[i].radius = 1;
+            hcold[i].mat = 0;
+        }
+    }
+    std::vector<MovingSphereRec<F>> hms(s->num_moving_spheres > 0 ? s->num_moving_spheres : 1);
+    for (int i = 0; i < s->num_moving_spheres; ++i) {
+        if (!check_mat(msp[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: moving sphere material index out of range");
+        MovingSphereRec<F> m = {};
+        F t0 = (F)msp[i].time0, t1 = (F)msp[i].time1, r = (F)msp[i].radius; // moving_sphere.h:11-12
+        for (int k = 0; k < 3; ++k) {
+            m.c0[k] = msp[i].center0[k];
+            m.dc[k] = msp[i].center1[k] - msp[i].center0[k];
+        }
+        m.t0 = t0;
+        m.dt = t1 - t0;
+        m.r2 = r * r;
+        m.radius = r;
+        m.mat = msp[i].material_idx;
+        hms[i] = m;
+    }
+    std::vector<TriangleRec<F>> htri(s->num_triangles > 0 ? s->num_triangles : 1);
+    for (int i = 0; i < s->num_triangles; ++i) {
+        if (!check_mat(tri[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: triangle material index out of range");
+        TriangleRec<F> t = {};
+        F e1[3], e2[3], u1[3], u2[3], cr[3];
+        for (int k = 0; k < 3; ++k) {
+            t.v0[k] = tri[i].vertices[0][k];
+            e1[k] = tri[i].vertices[1][k] - tri[i].vertices[0][k];
+            e2[k] = tri[i].vertices[2][k] - tri[i].vertices[0][k];
+            t.e1[k] = e1[k];
+            t.e2[k] = e2[k];
+        }
+        // triangle.h:9-15: unit(cross(unit(v1-v0), unit(v2-v0)))
+        pack_unit<F>(e1, u1);
+        pack_unit<F>(e2, u2);
+        cr[0] = u1[1] * u2[2] - u1[2] * u2[1];
+        cr[1] = u1[2] * u2[0] - u1[0] * u2[2];
+        cr[2] = u1[0] * u2[1] - u1[1] * u2[0];
+        pack_unit<F>(cr, t.n);
+        t.mat = tri[i].material_idx;
+        htri[i] = t;
+    }
+
+    RRTX_HIP(hipSetDevice(c->device));
+    void *old[5] = {c->d_hot, c->d_cold, c->d_msph, c->d_tri, c->d_mat};
+    for (void *p : old)
+        if (p) (void)hipFree(p);
+    c->d_hot = c->d_cold = c->d_msph = c->d_tri = c->d_mat = nullptr;
+    c->have_scene = false;
+
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        RRTX_HIP(hipMalloc(dst, bytes));
+        RRTX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&c->d_hot, hhot.data(), hhot.size() * sizeof(SphereHot<F>)))) return rc;
+    if ((rc = up(&c->d_cold, hcold.data(), hcold.size() * sizeof(SphereCold<F>)))) return rc;
+    if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
+    if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
+    if ((rc = up(&c->d_mat, hmat.data(), hmat.size() * sizeof(MaterialRec<F>)))) return rc;
+    c->n_sph = s->num_spheres;
+    c->n_sph_padded = n_pad;
+    c->n_msph = s->num_moving_spheres;
+    c->n_tri = s->num_triangles;
+    c->n_mat = s->num_materials;
+    c->have_scene = true;
+    return RRTX_OK;
+}
+
+template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
+{
+    KernelParams<F> P = {};
+    P.sph_hot = (const SphereHot<F> *)c->d_hot;
+    P.sph_cold = (const SphereCold<F> *)c->d_cold;
+    P.msph = (const MovingSphereRec<F> *)c->d_msph;
+    P.tri = (const TriangleRec<F> *)c->d_tri;
+    P.mat = (const MaterialRec<F> *)c->d_mat;
+    P.n_sph = c->n_sph, P.n_sph_padded = c->n_sph_padded, P.n_msph = c->n_msph, P.n_tri = c->n_tri;
+    memcpy(&P.cam, c->cam_bytes, sizeof(CameraRec<F>));
+    P.W = c->p.image_width, P.H = c->p.image_height, P.spp = c->p.samples_per_pixel, P.max_depth = c->p.max_depth;
+    P.seed = c->p.seed;
+    P.chunk = c->chunk, P.chunks_per_pixel = c->chunks_per_pixel;
+    P.local_rows = c->local_rows;
+    P.tile_rows = c->p.tile_rows, P.shard_rank = c->p.shard_rank, P.shard_count = c->p.shard_count;
+    P.total_tasks = c->total_tasks;
+    P.queue = c->d_queue;
+    P.out = (F *)out;
+    P.counters = c->d_counters;
+    P.collect_stats = c->p.collect_stats;
+    return P;
+}
+
+int drain_events(rrtx_ctx *c, double *last_ms)
+{
+    for (int i = 0; i < c->ev_pending; ++i) {
+        RRTX_HIP(hipEventSynchronize(c->ev_stop[i]));
+        float ms = 0.f;
+        RRTX_HIP(hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
+        c->kernel_ms_total += ms;
+        c->renders_total += 1;
+        if (last_ms) *last_ms = ms;
+    }
+    c->ev_pending = 0;
+    return RRTX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rrtx_version(void) { return RRTX_VERSION_STRING; }
+const char *rrtx_last_error(void) { return g_error.c_str(); }
+
+int rrtx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rrtx_runtime_version(void)
+{
+    int v = -1;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) return -1;
+    return v;
+}
+
+int rrtx_query(int device, rrtx_devinfo *out)
+{
+    if (!out) return fail(RRTX_E_INVALID, "rrtx_query: null output");
+    hipDeviceProp_t prop;
+    RRTX_HIP(hipGetDeviceProperties(&prop, device));
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", prop.name);
+    out->major = prop.major, out->minor = prop.minor;
+    out->multi_processor_count = prop.multiProcessorCount;
+    out->shared_mem_per_block = (int64_t)prop.sharedMemPerBlock;
+    out->max_threads_per_block = prop.maxThreadsPerBlock;
+    out->max_threads_per_multiprocessor = prop.maxThreadsPerMultiProcessor;
+    out->unified_addressing = 1;
+    out->l2_cache_size = prop.l2CacheSize;
+    out->total_global_mem = (int64_t)prop.totalGlobalMem;
+    out->clock_khz = prop.clockRate;
+    return RRTX_OK;
+}
+
+int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
+{
+    if (!params || !out) return fail(RRTX_E_INVALID, "rrtx_create: null argument");
+    *out = nullptr;
+    rrtx_params p = *params;
+    if (p.image_width < 2 || p.image_height < 2) return fail(RRTX_E_INVALID, "rrtx_create: image must be at least 2x2 (u = (i+xi)/(w-1), rrt.cu:112)");
+    if (p.samples_per_pixel < 1) return fail(RRTX_E_INVALID, "rrtx_create: samples_per_pixel must be >= 1");
+    if ((int64_t)p.image_width * p.image_height > (int64_t)1 << 30) return fail(RRTX_E_INVALID, "rrtx_create: image too large");
+    if (p.shard_count < 1) p.shard_count = 1;
+    if (p.tile_rows < 1) p.tile_rows = 1;
+    if (p.shard_rank < 0 || p.shard_rank >= p.shard_count) return fail(RRTX_E_INVALID, "rrtx_create: shard_rank out of range");
+    if (p.seed == 0) p.seed = 1984u;
+
+    int ndev = 0;
+    RRTX_HIP(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(RRTX_E_DEVICE, "rrtx_create: no HIP device present (this path has no CPU fallback)");
+    if (p.device < 0 || p.device >= ndev) return fail(RRTX_E_INVALID, "rrtx_create: device ordinal out of range");
+    RRTX_HIP(hipSetDevice(p.device));
+
+    rrtx_ctx *c = new rrtx_ctx();
+    c->p = p;
+    c->device = p.device;
+    c->fsize = p.fp64 ? 8 : 4;
+    c->local_rows = rows_of_shard(p, nullptr);
+
+    // samples per work item: a function of (w, h, spp) only, so that the summation shape — and
+    // with it the image — does not depend on how many devices share the frame.
+    const int64_t pixels_full = (int64_t)p.image_width * p.image_height;
+    int chunk = p.sample_chunk;
+    if (chunk < 0 || chunk >= p.samples_per_pixel)
+        chunk = p.samples_per_pixel;
+    else if (chunk == 0) {
+        chunk = p.samples_per_pixel > 8 ? 8 : p.samples_per_pixel;
+        // keep the partial buffer of a full frame under 2 GiB and the task count under 2^31
+        for (;;) {
+            int64_t cpp = (p.samples_per_pixel + chunk - 1) / chunk;
+            if (pixels_full * cpp * 3 * 8 <= ((int64_t)1 << 31) || chunk >= p.samples_per_pixel) break;
+            chunk *= 2;
+        }
+        if (chunk > p.samples_per_pixel) chunk = p.samples_per_pixel;
+    }
+    c->chunk = chunk;
+    c->chunks_per_pixel = (p.samples_per_pixel + chunk - 1) / chunk;
+    const int64_t tasks = (int64_t)c->local_rows * p.image_width * c->chunks_per_pixel;
+    if (tasks >= ((int64_t)1 << 31)) {
+        delete c;
+        return fail(RRTX_E_INVALID, "rrtx_create: too many work items; raise sample_chunk");
+    }
+    c->total_tasks = (uint32_t)tasks;
+
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, p.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_counters, 256);
+    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 256);
+    if (e == hipSuccess && c->chunks_per_pixel > 1) e = hipMalloc(&c->d_partial, (size_t)c->total_tasks * 3 * c->fsize + 64);
+    for (int i = 0; i < kEventRing && e == hipSuccess; ++i) {
+        e = hipEventCreate(&c->ev_start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev_stop[i]);
+    }
+    int bpc = 0;
+    if (e == hipSuccess) e = p.fp64 ? render_occupancy<double>(&bpc) : render_occupancy<float>(&bpc);
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "rrtx_create: HIP error = %u (%s)", (unsigned)e, hipGetErrorString(e));
+        rrtx_destroy(c);
+        return fail(RRTX_E_DEVICE, buf);
+    }
+    c->num_cus = prop.multiProcessorCount;
+    c->blocks_per_cu = bpc < 1 ? 1 : bpc;
+    // persistent grid: fill the chip once; never more blocks than there are task batches
+    int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
+    const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
+    const int64_t need_blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    c->grid_blocks = (int)grid;
+    *out = c;
+    return RRTX_OK;
+}
+
+void rrtx_destroy(rrtx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_hot, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (int i = 0; i < kEventRing; ++i) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
+{
+    if (!c || !s) return fail(RRTX_E_INVALID, "rrtx_set_scene: null argument");
+    if ((s->fp64 != 0) != (c->p.fp64 != 0)) return fail(RRTX_E_INVALID, "rrtx_set_scene: scene precision differs from the context's");
+    if (!s->camera) return fail(RRTX_E_INVALID, "rrtx_set_scene: no camera");
+    if (s->num_materials < 1 || !s->materials) return fail(RRTX_E_INVALID, "rrtx_set_scene: no materials");
+    if (s->num_spheres < 0 || s->num_moving_spheres < 0 || s->num_triangles < 0) return fail(RRTX_E_INVALID, "rrtx_set_scene: negative count");
+    if ((s->num_spheres && !s->spheres) || (s->num_moving_spheres && !s->moving_spheres) || (s->num_triangles && !s->triangles))
+        return fail(RRTX_E_INVALID, "rrtx_set_scene: count without table");
+    if ((int64_t)s->num_spheres + s->num_moving_spheres + s->num_triangles > (1 << 28)) return fail(RRTX_E_INVALID, "rrtx_set_scene: too many primitives");
+    if (c->stream) RRTX_HIP(hipStreamSynchronize(c->stream));
+    return c->p.fp64 ? upload_scene<double>(c, s) : upload_scene<float>(c, s);
+}
+
+int rrtx_shard_rows(const rrtx_ctx *c, int32_t *rows, int cap)
+{
+    if (!c) return fail(RRTX_E_INVALID, "rrtx_shard_rows: null context");
+    std::vector<int32_t> r;
+    int n = rows_of_shard(c->p, &r);
+    if (rows)
+        for (int i = 0; i < n && i < cap; ++i) rows[i] = r[i];
+    return n;
+}
+
+int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
+{
+    if (!c || !d_rows) return fail(RRTX_E_INVALID, "rrtx_render_device: null argument");
+    if (!c->have_scene) return fail(RRTX_E_NO_SCENE, "rrtx_render_device: no scene set");
+    RRTX_HIP(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->ev_pending == kEventRing) {
+        int rc = drain_events(c, nullptr);
+        if (rc) return rc;
+    }
+    if (c->total_tasks == 0) return RRTX_OK;
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 4, st));
+    if (c->p.collect_stats) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 8, st));
+    const int slot = c->ev_pending;
+    RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
+    void *out = c->chunks_per_pixel > 1 ? c->d_partial : d_rows;
+    if (c->p.fp64) {
+        KernelParams<double> P = make_params<double>(c, out);
+        RRTX_HIP(launch_render<double>(P, c->grid_blocks, st));
+        if (c->chunks_per_pixel > 1)
+            RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
+    }
+    else {
+        KernelParams<float> P = make_params<float>(c, out);
+        RRTX_HIP(launch_render<float>(P, c->grid_blocks, st));
+        if (c->chunks_per_pixel > 1)
+            RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
+    }
+    RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));
+    c->ev_pending = slot + 1;
+    return RRTX_OK;
+}
+
+int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
+{
+    if (!c) return fail(RRTX_E_INVALID, "rrtx_collect: null context");
+    RRTX_HIP(hipSetDevice(c->device));
+    double last_ms = 0.0;
+    const double before_total = c->kernel_ms_total;
+    const long before_n = c->renders_total;
+    int rc = drain_events(c, &last_ms);
+    if (rc) return rc;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->kernel_ms = last_ms;
+        stats->kernel_ms_sum = c->kernel_ms_total - before_total;
+        stats->renders = (int32_t)(c->renders_total - before_n);
+        stats->wall_ms = c->last_wall_ms;
+        stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
+        if (c->p.collect_stats) {
+            unsigned long long seg = 0;
+            RRTX_HIP(hipMemcpy(&seg, c->d_counters, sizeof seg, hipMemcpyDeviceToHost));
+            stats->segments = seg;
+            const uint64_t nprim = (uint64_t)c->n_sph + c->n_msph + c->n_tri;
+            stats->prim_tests = seg * nprim;
+            // B_prim = 4 scalars (sphere) / 9 scalars (moving sphere, triangle)
+            stats->bytes_algorithmic = seg * ((uint64_t)c->n_sph * 4 + (uint64_t)(c->n_msph + c->n_tri) * 9) * c->fsize +
+                                       (uint64_t)c->local_rows * c->p.image_width * 3 * c->fsize;
+        }
+        stats->grid_blocks = c->grid_blocks;
+        stats->block_threads = kBlockThreads;
+        stats->sample_chunk = c->chunk;
+        stats->local_rows = c->local_rows;
+    }
+    return RRTX_OK;
+}
+
+int rrtx_render(rrtx_ctx *c, void *fb, rrtx_stats *stats)
+{
+    if (!c || !fb) return fail(RRTX_E_INVALID, "rrtx_render: null argument");
+    if (!c->have_scene) return fail(RRTX_E_NO_SCENE, "rrtx_render: no scene set");
+    RRTX_HIP(hipSetDevice(c->device));
+    const size_t row_bytes = (size_t)c->p.image_width * 3 * c->fsize;
+    const size_t bytes = row_bytes * (size_t)c->local_rows;
+    if (!c->d_rows && bytes) RRTX_HIP(hipMalloc(&c->d_rows, bytes));
+    auto t0 = std::chrono::steady_clock::now();
+    if (bytes) {
+        int rc = rrtx_render_device(c, c->d_rows, nullptr);
+        if (rc) return rc;
+    }
+    RRTX_HIP(hipStreamSynchronize(c->stream));
+    auto t1 = std::chrono::steady_clock::now();
+    c->last_wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (bytes) {
+        std::vector<unsigned char> host(bytes);
+        RRTX_HIP(hipMemcpy(host.data(), c->d_rows, bytes, hipMemcpyDeviceToHost));
+        std::vector<int32_t> rows;
+        rows_of_shard(c->p, &rows);
+        for (size_t k = 0; k < rows.size(); ++k) memcpy((unsigned char *)fb + (size_t)rows[k] * row_bytes, host.data() + k * row_bytes, row_bytes);
+    }
+    return rrtx_collect(c, stats);
+}
+
+} // extern "C"

@@ -1,0 +1,83 @@
+// Device-side data layout of the render path (shared by the packer in rrtx_api.cpp and the
+// kernels in rrtx_kernels.hip).  See DESIGN.md "Data layout in HBM".
+//
+// The reference keeps every primitive as a heap object behind a vtable (rrt.cu:124-174); here the
+// world is a handful of flat, read-only arrays:
+//   * sphere "hot" records  {cx, cy, cz, r*r}            16 B (fp32) / 32 B (fp64)   — the only bytes
+//     the brute-force scan touches per test; read with wave-uniform scalar loads (4 SGPRs)
+//   * sphere "cold" records {radius, material}           — read once per hit
+//   * moving-sphere / triangle records with everything that sphere.h / moving_sphere.h /
+//     triangle.h recompute per call but that depends on the primitive only (c1-c0, t1-t0, r*r,
+//     edge1, edge2, face normal) hoisted to the host — same IEEE operation, same operands, so
+//     bit-identical to evaluating it per ray
+//   * material records {albedo rgb, fuzz|ir, type}
+#ifndef RRTX_DEVICE_H
+#define RRTX_DEVICE_H
+
+#include <stdint.h>
+
+namespace rrtx {
+
+constexpr int kSphereUnroll = 8;  // sphere table is padded to a multiple of this
+constexpr int kCandCap = 16;      // candidate slots per lane (LDS), flushed when nearly full
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr uint32_t kTaskBatch = 64; // tasks a wave pulls from the global queue at a time
+
+template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
+    F cx, cy, cz, r2;
+};
+template <typename F> struct alignas(2 * sizeof(F)) SphereCold {
+    F radius;
+    int32_t mat;
+};
+template <typename F> struct MovingSphereRec {
+    F c0[3];
+    F dc[3];  // center1 - center0            (moving_sphere.h:29)
+    F t0, dt; // time0, time1 - time0         (moving_sphere.h:29)
+    F r2;     // radius * radius              (moving_sphere.h:38)
+    F radius;
+    int32_t mat;
+};
+template <typename F> struct TriangleRec {
+    F v0[3];
+    F e1[3]; // vertices[1] - vertices[0]     (triangle.h:39)
+    F e2[3]; // vertices[2] - vertices[0]     (triangle.h:40)
+    F n[3];  // get_normal()                  (triangle.h:9-15)
+    int32_t mat;
+};
+template <typename F> struct alignas(4 * sizeof(F)) MaterialRec {
+    F r, g, b;
+    F param; // metal: min(fuzz,1) (material.h:48) | dielectric: ir
+    int32_t type;
+    int32_t pad[3];
+};
+template <typename F> struct CameraRec { // camera.h:43-48
+    F origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    F lens_radius, time0, time1;
+};
+
+template <typename F> struct KernelParams {
+    const SphereHot<F> *sph_hot; // n_sph_padded records
+    const SphereCold<F> *sph_cold;
+    const MovingSphereRec<F> *msph;
+    const TriangleRec<F> *tri;
+    const MaterialRec<F> *mat;
+    int32_t n_sph, n_sph_padded, n_msph, n_tri;
+    CameraRec<F> cam;
+    int32_t W, H, spp, max_depth;
+    uint32_t seed;
+    int32_t chunk;           // samples per task
+    int32_t chunks_per_pixel;
+    // shard: local row lr -> global row ((lr / tile_rows) * shard_count + shard_rank) * tile_rows + lr % tile_rows
+    int32_t local_rows, tile_rows, shard_rank, shard_count;
+    uint32_t total_tasks;    // local_rows * W * chunks_per_pixel
+    uint32_t *queue;         // global task cursor (zeroed before every launch)
+    F *out;                  // [total_tasks][3]: per-task partial sums (== the local frame when chunks_per_pixel == 1)
+    unsigned long long *counters; // [0] segments (only if collect_stats)
+    int32_t collect_stats;
+};
+
+} // namespace rrtx
+
+#endif

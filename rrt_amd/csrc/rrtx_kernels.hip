@@ -1,0 +1,553 @@
+// Render megakernel for gfx950 (MI355X).  Replaces render_init + cuda_render + ray_color and all
+// the virtual hit()/scatter() calls behind them (rrt.cu:42-122, hittable_list.h:95-117,
+// sphere.h:33-58, moving_sphere.h:27-58, triangle.h:35-75, material.h:21-109, camera.h:31-38).
+//
+// Shape of the computation (DESIGN.md "Kernel"):
+//   * persistent waves; a work item ("task") is (pixel, chunk of consecutive samples).  Waves pull
+//     batches of tasks from one global cursor and hand them to lanes with a wave64 ballot +
+//     prefix-popcount, so a lane whose task is finished starts the next one in the same loop
+//     iteration — every live lane always carries a ray into the primitive scan.
+//   * the scan is the reference's linear hittable_list scan.  Phase 1 walks the sphere table with
+//     WAVE-UNIFORM SCALAR LOADS (16 B/sphere into SGPRs, no VGPR or LDS traffic) and evaluates only
+//     the discriminant; lanes whose discriminant is not negative append the primitive index to a
+//     per-lane candidate list in LDS.  Phase 2 lets every lane walk ITS OWN short list and run the
+//     exact root / range / tie logic of the reference, in list (= primitive) order, so the result is
+//     identical to the sequential scan with its shrinking t_max, including "a later sphere wins an
+//     exact tie" (sphere.h:46-48) and the strict range of triangles (triangle.h:63).
+//   * no FMA contraction anywhere (-ffp-contract=off): rrtc's fp32 image depends on unfused
+//     rounding, most visibly in c = |oc|^2 - r^2 on the r = 1000 ground sphere.
+//   * counter-based RNG keyed by (seed, global pixel index, sample) — no state in memory, no
+//     render_init, identical image for any sharding of the frame.
+//
+// No MFMA: there is no dense contraction on this path (BASELINE.json north_star).
+#include <hip/hip_runtime.h>
+
+#include "rrtx_device.h"
+
+namespace rrtx {
+
+#define RRTX_DEV __device__ __forceinline__
+#define RRTX_CONST_AS __attribute__((address_space(4)))
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers — operation order mirrors vec3.h (it is part of the fp32 image)
+// ---------------------------------------------------------------------------------------------
+template <typename F> struct V3 {
+    F x, y, z;
+};
+template <typename F> RRTX_DEV V3<F> mk(F x, F y, F z) { return V3<F>{x, y, z}; }
+template <typename F> RRTX_DEV V3<F> ld3(const F *p) { return V3<F>{p[0], p[1], p[2]}; }
+template <typename F> RRTX_DEV V3<F> vadd(V3<F> a, V3<F> b) { return mk<F>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename F> RRTX_DEV V3<F> vsub(V3<F> a, V3<F> b) { return mk<F>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename F> RRTX_DEV V3<F> vmul(V3<F> a, V3<F> b) { return mk<F>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename F> RRTX_DEV V3<F> vscale(F t, V3<F> v) { return mk<F>(t * v.x, t * v.y, t * v.z); } // vec3.h:109
+template <typename F> RRTX_DEV V3<F> vneg(V3<F> a) { return mk<F>(-a.x, -a.y, -a.z); }
+template <typename F> RRTX_DEV V3<F> vdiv(V3<F> v, F t) { return vscale<F>((F)1 / t, v); }             // vec3.h:113
+template <typename F> RRTX_DEV F vdot(V3<F> a, V3<F> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.h:115
+template <typename F> RRTX_DEV V3<F> vcross(V3<F> u, V3<F> v)                                         // vec3.h:117-121
+{
+    return mk<F>(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+template <typename F> RRTX_DEV F vlen2(V3<F> a) { return a.x * a.x + a.y * a.y + a.z * a.z; } // vec3.h:60
+
+RRTX_DEV float fsqrt(float x) { return __builtin_sqrtf(x); } // correctly rounded (hipcc default)
+RRTX_DEV double fsqrt(double x) { return __builtin_sqrt(x); }
+RRTX_DEV float ffabs(float x) { return __builtin_fabsf(x); }
+RRTX_DEV double ffabs(double x) { return __builtin_fabs(x); }
+RRTX_DEV float ffmin(float a, float b) { return __builtin_fminf(a, b); }
+RRTX_DEV double ffmin(double a, double b) { return __builtin_fmin(a, b); }
+template <typename F> RRTX_DEV V3<F> vunit(V3<F> v) { return vdiv<F>(v, fsqrt(vlen2(v))); } // vec3.h:125
+
+// POW(1-cosine, 5) of material.h:108.  rrtc calls powf(); x^5 formed in double from a float x is
+// exact up to 2 ulp(double) and rounds to the same float except within 2^-28 of a rounding
+// boundary; the value only feeds the comparison against a uniform draw (material.h:89).
+RRTX_DEV float pow5(float x)
+{
+    double d = (double)x;
+    double d2 = d * d;
+    return (float)(d2 * d2 * d);
+}
+RRTX_DEV double pow5(double x)
+{
+    double x2 = x * x;
+    return x2 * x2 * x;
+}
+
+template <typename F> struct SphereUnroll;
+template <> struct SphereUnroll<float> {
+    static constexpr int value = kSphereUnroll; // 8 x 16 B = 32 SGPRs per block
+};
+template <> struct SphereUnroll<double> {
+    static constexpr int value = kSphereUnroll / 2; // 4 x 32 B = 32 SGPRs per block
+};
+template <typename F> struct Limits;
+template <> struct Limits<float> {
+    static RRTX_DEV float inf() { return __builtin_huge_valf(); }
+};
+template <> struct Limits<double> {
+    static RRTX_DEV double inf() { return __builtin_huge_val(); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// RNG (DESIGN.md "RNG"; oracle/rrt_oracle.cpp holds the CPU statement of the same generator)
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t k0, k1, n;
+};
+RRTX_DEV uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x21F0AAADu;
+    x ^= x >> 15;
+    x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
+}
+RRTX_DEV void rng_open(Rng &r, uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint64_t z = ((uint64_t)pixel << 32) | (uint64_t)sample;
+    z += (uint64_t)seed * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    r.k0 = (uint32_t)z;
+    r.k1 = (uint32_t)(z >> 32);
+    r.n = 0;
+}
+template <typename F> RRTX_DEV F rng_uniform(Rng &r);
+template <> RRTX_DEV float rng_uniform<float>(Rng &r)
+{
+    uint32_t hi = mix32(r.k0 + r.n * 0x9E3779B9u) + r.k1;
+    r.n += 1;
+    return (float)(hi >> 8) * 0x1p-24f;
+}
+template <> RRTX_DEV double rng_uniform<double>(Rng &r)
+{
+    uint32_t hi = mix32(r.k0 + r.n * 0x9E3779B9u) + r.k1;
+    uint32_t lo = mix32(r.k1 + r.n * 0x85EBCA6Bu) + r.k0;
+    r.n += 1;
+    return (double)(((uint64_t)hi << 21) | (uint64_t)(lo >> 11)) * 0x1p-53;
+}
+// rtweekend.h:70-74
+template <typename F> RRTX_DEV F rng_range(Rng &r, F lo, F hi) { return lo + (hi - lo) * rng_uniform<F>(r); }
+
+// vec3.h:136-143, components drawn x, y, z
+template <typename F> RRTX_DEV V3<F> in_unit_sphere(Rng &r)
+{
+    V3<F> p;
+    do {
+        p.x = rng_range<F>(r, (F)-1, (F)1);
+        p.y = rng_range<F>(r, (F)-1, (F)1);
+        p.z = rng_range<F>(r, (F)-1, (F)1);
+    } while (vlen2(p) >= 1);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-lane path state
+// ---------------------------------------------------------------------------------------------
+template <typename F> struct Path {
+    V3<F> o, d;   // current ray (ray.h)
+    F tm;         // ray time
+    V3<F> atten;  // running attenuation, rrt.cu:46,58
+    int depth;    // bounce index i of rrt.cu:47
+};
+
+template <typename F> struct HitInfo {
+    F t;
+    int idx; // unified primitive index: spheres [0,n_sph), moving [n_sph_padded, +n_msph), triangles after
+};
+
+// Exact per-candidate test, reference order.  Spheres: sphere.h:33-49.
+template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, HitInfo<F> &best)
+{
+    F ocx = p.o.x - cx, ocy = p.o.y - cy, ocz = p.o.z - cz;
+    F half_b = ocx * p.d.x + ocy * p.d.y + ocz * p.d.z;
+    F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+    F disc = half_b * half_b - a * c;
+    if (disc < 0) return;
+    F sq = fsqrt(disc);
+    F root = (-half_b - sq) / a;
+    if (root < t_min || best.t < root) {
+        root = (-half_b + sq) / a;
+        if (root < t_min || best.t < root) return;
+    }
+    best.t = root;
+    best.idx = idx;
+}
+
+template <typename F> RRTX_DEV V3<F> msphere_center(const MovingSphereRec<F> &m, F tm) // moving_sphere.h:27-30
+{
+    F s = (tm - m.t0) / m.dt;
+    return mk<F>(m.c0[0] + s * m.dc[0], m.c0[1] + s * m.dc[1], m.c0[2] + s * m.dc[2]);
+}
+
+// triangle.h:35-75.  stage 0: up to the u/v rejections (phase 1); stage 1: full test (phase 2).
+template <typename F, bool FULL> RRTX_DEV bool triangle_test(const TriangleRec<F> &tr, const Path<F> &p, F t_min, F t_max, F &t_out)
+{
+    const F EPS = (F)0.0000001;
+    V3<F> e1 = ld3<F>(tr.e1), e2 = ld3<F>(tr.e2);
+    V3<F> h = vcross<F>(p.d, e2);
+    F a = vdot<F>(e1, h);
+    if (a > -EPS && a < EPS) return false;
+    F f = (F)1.0 / a;
+    V3<F> s = vsub<F>(p.o, ld3<F>(tr.v0));
+    F u = vdot<F>(vscale<F>(f, s), h);
+    if (u < (F)0.0 || u > (F)1.0) return false;
+    V3<F> q = vcross<F>(s, e1);
+    F v = vdot<F>(vscale<F>(f, p.d), q);
+    if (v < (F)0.0 || u + v > (F)1.0) return false;
+    if (!FULL) return true;
+    F t = vdot<F>(vscale<F>(f, e2), q);
+    if (t > EPS && (t > t_min) && (t < t_max)) {
+        t_out = t;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
+{
+    __shared__ uint32_t cand_lds[kWavesPerBlock][kCandCap][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t *const my_cand = &cand_lds[wave][0][lane]; // slot s at my_cand[s * 64]: bank == lane, conflict-free
+
+    typedef const RRTX_CONST_AS SphereHot<F> *HotPtr; // constant address space => s_load for uniform indices
+    const HotPtr sph_scalar = (HotPtr)P.sph_hot;
+
+    const F t_min = (F)0.001; // rrt.cpp:32 typing
+    const int n_sph = P.n_sph, n_sph_pad = P.n_sph_padded, n_msph = P.n_msph, n_tri = P.n_tri;
+    const int msph_base = n_sph_pad, tri_base = n_sph_pad + n_msph;
+
+    // wave-uniform task pool
+    uint32_t pool_next = 0, pool_end = 0;
+    bool queue_dry = false;
+
+    // lane state
+    bool alive = true, need_task = true, need_ray = false;
+    uint32_t task = 0;
+    int px_i = 0, px_j = 0, s_cur = 0, s_end = 0;
+    V3<F> acc = mk<F>(0, 0, 0);
+    Path<F> path;
+    path.o = path.d = path.atten = mk<F>(0, 0, 0);
+    path.tm = 0;
+    path.depth = 0;
+    Rng rng = {0, 0, 0};
+    uint32_t n_segments = 0;
+
+    for (;;) {
+        // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
+        uint64_t want = __ballot(need_task);
+        while (want != 0ull) {
+            if (pool_next == pool_end) {
+                if (queue_dry) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.queue, kTaskBatch);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= P.total_tasks) {
+                    queue_dry = true;
+                    break;
+                }
+                pool_next = base;
+                pool_end = (P.total_tasks - base < kTaskBatch) ? P.total_tasks : base + kTaskBatch;
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u)); // set bits below this lane
+            if (need_task && rank < avail) {
+                task = pool_next + rank;
+                need_task = false;
+                // task -> (local pixel, sample chunk)
+                const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
+                const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
+                const uint32_t lr = q / (uint32_t)P.W;
+                px_i = (int)(q - lr * (uint32_t)P.W);
+                const uint32_t tile = lr / (uint32_t)P.tile_rows;
+                px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
+                s_cur = (int)c * P.chunk;
+                s_end = s_cur + P.chunk < P.spp ? s_cur + P.chunk : P.spp;
+                acc = mk<F>(0, 0, 0);
+                need_ray = true;
+            }
+            const uint32_t wanted = (uint32_t)__popcll(want);
+            pool_next += wanted < avail ? wanted : avail;
+            want = __ballot(need_task);
+        }
+        if (need_task) { // queue exhausted: this lane retires
+            alive = false;
+            need_task = false;
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        if (alive) {
+            // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
+            if (need_ray) {
+                need_ray = false;
+                rng_open(rng, P.seed, (uint32_t)(px_j * P.W + px_i), (uint32_t)s_cur);
+                const F u = ((F)px_i + rng_uniform<F>(rng)) / (F)(P.W - 1);
+                const F v = ((F)px_j + rng_uniform<F>(rng)) / (F)(P.H - 1);
+                F dx, dy;
+                do { // random_in_unit_disk, vec3.h:127-134
+                    dx = rng_range<F>(rng, (F)-1, (F)1);
+                    dy = rng_range<F>(rng, (F)-1, (F)1);
+                } while (dx * dx + dy * dy >= 1); // + 0*0 of the z component changes nothing
+                const F rdx = P.cam.lens_radius * dx, rdy = P.cam.lens_radius * dy;
+                const V3<F> offset = vadd<F>(vscale<F>(rdx, ld3<F>(P.cam.u)), vscale<F>(rdy, ld3<F>(P.cam.v)));
+                const V3<F> org = ld3<F>(P.cam.origin);
+                path.o = vadd<F>(org, offset);
+                path.d = vsub<F>(vsub<F>(vadd<F>(vadd<F>(ld3<F>(P.cam.llc), vscale<F>(u, ld3<F>(P.cam.horizontal))), vscale<F>(v, ld3<F>(P.cam.vertical))), org), offset);
+                path.tm = rng_range<F>(rng, P.cam.time0, P.cam.time1);
+                path.atten = mk<F>(1, 1, 1);
+                path.depth = 0;
+            }
+
+            bool done = false;
+            V3<F> radiance = mk<F>(0, 0, 0);
+            if (P.max_depth <= 0) { // rrt.cu:47 loop body never runs
+                done = true;
+            }
+            else {
+            // ---------------- closest hit: hittable_list.h:95-117 ---------------------------------
+            n_segments += 1;
+            const F a = vlen2<F>(path.d); // sphere.h:36
+            HitInfo<F> best;
+            best.t = Limits<F>::inf();
+            best.idx = -1;
+            uint32_t cnt = 0;
+
+            // phase 2 body, used for flushes and at the end
+            auto drain = [&]() {
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    const int k = (int)my_cand[s * 64];
+                    if (k < msph_base) {
+                        if (k < n_sph) {
+                            const SphereHot<F> g = P.sph_hot[k];
+                            refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, k, best);
+                        }
+                    }
+                    else if (k < tri_base) {
+                        const MovingSphereRec<F> m = P.msph[k - msph_base];
+                        const V3<F> cen = msphere_center<F>(m, path.tm);
+                        refine_sphere<F>(cen.x, cen.y, cen.z, m.r2, path, a, t_min, k, best);
+                    }
+                    else {
+                        F t;
+                        if (triangle_test<F, true>(P.tri[k - tri_base], path, t_min, best.t, t)) {
+                            best.t = t;
+                            best.idx = k;
+                        }
+                    }
+                }
+                cnt = 0;
+            };
+
+            // phase 1a: spheres, wave-uniform scalar loads.  The block of kUnroll tests is kept
+            // branch-free (all discriminants first, pushes afterwards) so that the scalar loads of a
+            // whole block are issued together and the VALU stream is one straight line.
+            constexpr int kUnroll = SphereUnroll<F>::value;
+            for (int k0 = 0; k0 < n_sph_pad; k0 += kUnroll) {
+                if (__ballot(cnt > (uint32_t)(kCandCap - kUnroll)) != 0ull) drain();
+                bool is_cand[kUnroll];
+                uint64_t any_cand = 0ull; // OR of the compare masks: scalar ALU only
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int k = k0 + u;
+                    const F cx = sph_scalar[k].cx, cy = sph_scalar[k].cy, cz = sph_scalar[k].cz, r2 = sph_scalar[k].r2;
+                    const F ocx = path.o.x - cx, ocy = path.o.y - cy, ocz = path.o.z - cz;
+                    const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;
+                    const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+                    const F disc = half_b * half_b - a * c;
+                    is_cand[u] = !(disc < 0);
+                    any_cand |= __ballot(is_cand[u]);
+                }
+                if (any_cand != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        if (is_cand[u]) {
+                            my_cand[cnt * 64] = (uint32_t)(k0 + u);
+                            cnt += 1;
+                        }
+                    }
+                }
+            }
+            // phase 1b: moving spheres (center depends on the ray's time: per-lane)
+            for (int m = 0; m < n_msph; ++m) {
+                if (__ballot(cnt >= (uint32_t)kCandCap) != 0ull) drain();
+                const MovingSphereRec<F> ms = P.msph[m];
+                const V3<F> cen = msphere_center<F>(ms, path.tm);
+                const F ocx = path.o.x - cen.x, ocy = path.o.y - cen.y, ocz = path.o.z - cen.z;
+                const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;
+                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - ms.r2;
+                const F disc = half_b * half_b - a * c;
+                if (!(disc < 0)) {
+                    my_cand[cnt * 64] = (uint32_t)(msph_base + m);
+                    cnt += 1;
+                }
+            }
+            // phase 1c: triangles
+            for (int t = 0; t < n_tri; ++t) {
+                if (__ballot(cnt >= (uint32_t)kCandCap) != 0ull) drain();
+                F dummy;
+                if (triangle_test<F, false>(P.tri[t], path, t_min, best.t, dummy)) {
+                    my_cand[cnt * 64] = (uint32_t)(tri_base + t);
+                    cnt += 1;
+                }
+            }
+            drain();
+
+            // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
+            if (best.idx < 0) {
+                // sky, rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50)
+                const V3<F> ud = vunit<F>(path.d);
+                const F t = (F)0.5 * (ud.y + (F)1.0);
+                const V3<F> c = vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0)));
+                radiance = vmul<F>(path.atten, c);
+                done = true;
+            }
+            else {
+                // hit record: sphere.h:51-55 / moving_sphere.h:50-55 / triangle.h:64-67
+                const V3<F> hp = vadd<F>(path.o, vscale<F>(best.t, path.d)); // ray.h:17
+                V3<F> outward;
+                int mat_idx;
+                if (best.idx < msph_base) {
+                    const SphereHot<F> g = P.sph_hot[best.idx];
+                    const SphereCold<F> cold = P.sph_cold[best.idx];
+                    outward = vdiv<F>(vsub<F>(hp, mk<F>(g.cx, g.cy, g.cz)), cold.radius);
+                    mat_idx = cold.mat;
+                }
+                else if (best.idx < tri_base) {
+                    const MovingSphereRec<F> m = P.msph[best.idx - msph_base];
+                    outward = vdiv<F>(vsub<F>(hp, msphere_center<F>(m, path.tm)), m.radius);
+                    mat_idx = m.mat;
+                }
+                else {
+                    const TriangleRec<F> &tr = P.tri[best.idx - tri_base];
+                    outward = ld3<F>(tr.n);
+                    mat_idx = tr.mat;
+                }
+                const bool front_face = vdot<F>(path.d, outward) < 0; // hittable.h:18
+                const V3<F> n = front_face ? outward : vneg<F>(outward);
+                const MaterialRec<F> m = P.mat[mat_idx];
+                V3<F> new_d;
+                bool scattered = true;
+                V3<F> albedo = mk<F>(m.r, m.g, m.b);
+                if (m.type != 2) {
+                    const V3<F> rs = in_unit_sphere<F>(rng); // both lambertian and metal draw it (material.h:24,54)
+                    if (m.type == 0) {
+                        // lambertian, material.h:21-32
+                        new_d = vadd<F>(n, vunit<F>(rs));
+                        const double tiny = 1e-8; // vec3.h:65 compares in double
+                        if (((double)ffabs(new_d.x) < tiny) && ((double)ffabs(new_d.y) < tiny) && ((double)ffabs(new_d.z) < tiny)) new_d = n;
+                    }
+                    else {
+                        // metal, material.h:50-57
+                        const V3<F> ud = vunit<F>(path.d);
+                        const V3<F> reflected = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n)); // vec3.h:156
+                        new_d = vadd<F>(reflected, vscale<F>(m.param, rs));
+                        scattered = vdot<F>(new_d, n) > 0;
+                    }
+                }
+                else {
+                    // dielectric, material.h:76-96
+                    albedo = mk<F>((F)1.0, (F)1.0, (F)1.0);
+                    const F ratio = front_face ? ((F)1.0 / m.param) : m.param;
+                    const V3<F> ud = vunit<F>(path.d);
+                    const F cos_theta = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
+                    const F sin_theta = fsqrt((F)1.0 - cos_theta * cos_theta);
+                    bool reflect_it = ratio * sin_theta > (F)1.0;
+                    if (!reflect_it) { // the uniform is drawn only here (short-circuit ||, material.h:89)
+                        F r0 = ((F)1 - ratio) / ((F)1 + ratio);
+                        r0 = r0 * r0;
+                        const F refl = r0 + ((F)1 - r0) * pow5((F)1 - cos_theta);
+                        reflect_it = refl > rng_uniform<F>(rng);
+                    }
+                    if (reflect_it)
+                        new_d = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n));
+                    else {
+                        // refract, vec3.h:158-164
+                        const F ct = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
+                        const V3<F> perp = vscale<F>(ratio, vadd<F>(ud, vscale<F>(ct, n)));
+                        const V3<F> par = vscale<F>(-fsqrt(ffabs((F)1.0 - vlen2<F>(perp))), n);
+                        new_d = vadd<F>(perp, par);
+                    }
+                }
+                if (scattered) {
+                    path.atten = vmul<F>(path.atten, albedo); // rrt.cu:58
+                    path.o = hp;
+                    path.d = new_d; // time unchanged (material.h:29)
+                    path.depth += 1;
+                    if (path.depth >= P.max_depth) done = true; // rrt.cu:47,78: radiance stays 0
+                }
+                else
+                    done = true; // absorbed, rrt.cu:65
+            }
+            } // max_depth > 0
+
+            if (done) {
+                acc = vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
+                s_cur += 1;
+                if (s_cur == s_end) {
+                    F *o = P.out + (size_t)task * 3;
+                    o[0] = acc.x;
+                    o[1] = acc.y;
+                    o[2] = acc.z;
+                    need_task = true;
+                }
+                else
+                    need_ray = true;
+            }
+        }
+    }
+
+    if (P.collect_stats) atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+}
+
+// Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
+// number of devices).  Only launched when chunks_per_pixel > 1.
+template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, uint32_t n_values, int chunks_per_pixel)
+{
+    // one thread per (pixel, channel) value: n_values = pixels * 3
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
+        const uint32_t q = v / 3u, ch = v - q * 3u;
+        const F *p = partial + ((size_t)q * chunks_per_pixel) * 3 + ch;
+        F s = 0;
+        for (int c = 0; c < chunks_per_pixel; ++c) s = s + p[(size_t)c * 3];
+        fb[v] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers (called from rrtx_api.cpp)
+// ---------------------------------------------------------------------------------------------
+template <typename F> hipError_t launch_render(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(render_kernel<F>, dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    return hipGetLastError();
+}
+template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32_t n_values, int chunks_per_pixel, hipStream_t stream)
+{
+    int blocks = (int)((n_values + 255u) / 256u);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, n_values, chunks_per_pixel);
+    return hipGetLastError();
+}
+template <typename F> hipError_t render_occupancy(int *blocks_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F>, kBlockThreads, 0);
+}
+
+template hipError_t launch_render<float>(const KernelParams<float> &, int, hipStream_t);
+template hipError_t launch_render<double>(const KernelParams<double> &, int, hipStream_t);
+template hipError_t launch_finalize<float>(const float *, float *, uint32_t, int, hipStream_t);
+template hipError_t launch_finalize<double>(const double *, double *, uint32_t, int, hipStream_t);
+template hipError_t render_occupancy<float>(int *);
+template hipError_t render_occupancy<double>(int *);
+
+} // namespace rrtx

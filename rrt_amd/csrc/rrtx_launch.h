@@ -1,0 +1,13 @@
+// Launch wrappers implemented in rrtx_kernels.hip (the only translation unit with device code).
+#ifndef RRTX_LAUNCH_H
+#define RRTX_LAUNCH_H
+#include <hip/hip_runtime_api.h>
+
+#include "rrtx_device.h"
+
+namespace rrtx {
+template <typename F> hipError_t launch_render(const KernelParams<F> &P, int grid_blocks, hipStream_t stream);
+template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32_t n_values, int chunks_per_pixel, hipStream_t stream);
+template <typename F> hipError_t render_occupancy(int *blocks_per_cu);
+} // namespace rrtx
+#endif
