@@ -1,0 +1,86 @@
+"""Row-tile sharding of one frame over the ranks of a torch.distributed job, and the final gather.
+
+One process per GPU.  The frame is cut into tiles of `tile_rows` rows; tile t belongs to rank
+t mod world (interleaving evens out the sky/ground cost gradient of the reference's scenes,
+SURVEY.md App. A).  There is no data-path communication while rendering; the only exchange is
+ONE gather of the per-rank row blocks to rank 0 (backend "nccl" = RCCL over xGMI on MI355X,
+"gloo" in the CPU tests), followed by an index_copy that puts rows where they belong.
+The RNG is keyed by the global pixel index, so the assembled frame is bit-identical for any
+(world, tile_rows).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(image_height, rank, world, tile_rows):
+    """Global row numbers owned by `rank` (ascending) - the same rule as rrtx_shard_rows()."""
+    rows = np.arange(image_height, dtype=np.int64)
+    return rows[(rows // max(1, tile_rows)) % max(1, world) == rank]
+
+
+def gather_frame(local_rows, image_height, tile_rows=4, group=None, dst=0):
+    """Collects every rank's compact row block on `dst` and returns the assembled frame there.
+
+    local_rows: tensor [n_local_rows, width, 3] holding this rank's rows in shard_rows() order.
+    Returns a tensor [image_height, width, 3] on rank `dst`, None elsewhere.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    width = local_rows.shape[1]
+    counts = [len(shard_rows(image_height, r, world, tile_rows)) for r in range(world)]
+    assert local_rows.shape[0] == counts[rank], "row block does not match this rank's shard"
+    if world == 1:
+        return local_rows
+    most = max(counts)
+    # equal-size messages: pad the short blocks (at most tile_rows rows of padding)
+    send = local_rows
+    if counts[rank] < most:
+        send = torch.zeros((most, width, 3), dtype=local_rows.dtype, device=local_rows.device)
+        send[: counts[rank]] = local_rows
+    send = send.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=parts, dst=dst, group=group)
+        frame = torch.empty((image_height, width, 3), dtype=local_rows.dtype, device=local_rows.device)
+        for r in range(world):
+            idx = torch.from_numpy(shard_rows(image_height, r, world, tile_rows)).to(frame.device)
+            frame.index_copy_(0, idx, parts[r][: counts[r]])
+        return frame
+    dist.gather(send, gather_list=None, dst=dst, group=group)
+    return None
+
+
+class ShardedRenderer:
+    """Rrt bound to this rank's shard, rendering into a torch CUDA tensor (no host round trip)."""
+
+    def __init__(self, scene_file, image_width, image_height, samples_per_pixel, max_depth=50, *, fp64=False, tile_rows=4, sample_chunk=0, seed=1984, group=None,
+                 device=None, collect_stats=True):
+        from .render import Rrt, Scene
+
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.h, self.w, self.spp = image_height, image_width, samples_per_pixel
+        self.tile_rows = tile_rows
+        self.scene = Scene(scene_file, image_width, image_height, fp64=fp64)
+        self.rrt = Rrt(image_width, image_height, samples_per_pixel, max_depth, use_bvh=False, fp64=fp64, device=self.device.index or 0, seed=seed, sample_chunk=sample_chunk,
+                       shard_rank=self.rank, shard_count=self.world, tile_rows=tile_rows, collect_stats=collect_stats)
+        self.rrt.set_scene(self.scene)
+        self.rows = self.rrt.shard_rows()
+        assert np.array_equal(self.rows, shard_rows(image_height, self.rank, self.world, tile_rows))
+        self.local = torch.zeros((len(self.rows), image_width, 3), dtype=torch.float64 if fp64 else torch.float32, device=self.device)
+
+    def render_local(self):
+        """Enqueue one render of this rank's rows on torch's current stream."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.rrt.render_device(self.local.data_ptr(), stream)
+        return self.local
+
+    def render(self, dst=0):
+        """One full step: render the shard, gather to `dst`.  Returns the frame on dst, None elsewhere."""
+        self.render_local()
+        if self.world == 1:
+            return self.local
+        return gather_frame(self.local, self.h, self.tile_rows, self.group, dst)

@@ -1,0 +1,83 @@
+"""The oracle against the LIVE compiled reference (oracle/_ref), where that exists.
+
+oracle/_ref is built from /root/reference by `make -C oracle ref`; it exists in the development
+container and travels to the GPU box as prebuilt files.  Elsewhere these tests skip and
+test_oracle_golden.py (committed fixtures from the same build) carries the pin.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from _oracle import GOLDEN, Oracle, Reference, have_reference, scene_path
+
+pytestmark = pytest.mark.skipif(not have_reference(), reason="oracle/_ref not built (needs /root/reference)")
+
+SCENES = {"test1": scene_path("test1"), "test2": scene_path("test2"), "test3": scene_path("test3"), "final": scene_path("final"), "xform": os.path.join(GOLDEN, "scenes", "xform.txt")}
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_live_bit_equality(name, fp64):
+    w, h, spp, depth, seed = 41, 27, 5, 50, 4242  # odd sizes, a seed the fixtures do not use
+    o = Oracle(SCENES[name], w, h, fp64)
+    r = Reference(SCENES[name], w, h, fp64)
+    to, tr = o.tables(), r.tables()
+    assert to.counts == tr.counts
+    for key in ("cam", "materials", "spheres", "msph", "tris"):
+        assert np.array_equal(getattr(to, key), getattr(tr, key)), key
+    fo, _ = o.render(spp, depth, seed, order=0)
+    assert np.array_equal(fo, r.render(spp, depth, seed))
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2])
+def test_shallow_depths(depth):
+    o = Oracle(SCENES["final"], 30, 20, False)
+    r = Reference(SCENES["final"], 30, 20, False)
+    assert np.array_equal(o.render(4, depth, 1984, order=0)[0], r.render(4, depth, 1984))
+
+
+def test_golden_files_are_current():
+    g = np.load(os.path.join(GOLDEN, "radiance_test2_f32.npy"))
+    assert np.array_equal(Reference(SCENES["test2"], 32, 20, False).render(3, 50, 1984), g)
+
+
+def test_reference_table_sizes_match_the_c_abi_structs():
+    # the C ABI's table structs must be layout-identical to what rrt.cu marshals (rrt.cu:217-247)
+    import rrt_amd.render as rr
+
+    for fp64 in (False, True):
+        sz = Reference(SCENES["test1"], 8, 8, fp64).sizeof()
+        dt = rr._table_dtypes(fp64)
+        assert sz[0] == (8 if fp64 else 4)
+        assert [dt["camera"].itemsize, dt["material"].itemsize, dt["sphere"].itemsize, dt["msphere"].itemsize, dt["triangle"].itemsize] == sz[1:]
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_product_parser_produces_the_reference_bytes(fp64):
+    # field-by-field equality of the product's tables with the reference's raw POD bytes
+    import rrt_amd
+    import rrt_amd.render as rr
+
+    dt = rr._table_dtypes(fp64)
+    for name, path in SCENES.items():
+        ref = Reference(path, 48, 32, fp64)
+        cam, mats, sph, msph, tris = ref.raw()
+        t = rrt_amd.Scene(path, 48, 32, fp64=fp64).tables()
+        rcam = np.frombuffer(cam.tobytes(), dtype=dt["camera"])[0]
+        for f in dt["camera"].names:
+            assert np.array_equal(rcam[f], t["camera"][f]), (name, f)
+        for key, raw, dkey in (("spheres", sph, "sphere"), ("moving_spheres", msph, "msphere"), ("triangles", tris, "triangle")):
+            r = np.frombuffer(raw.tobytes(), dtype=dt[dkey])
+            assert len(r) == len(t[key])
+            for f in dt[dkey].names:
+                assert np.array_equal(r[f], t[key][f]), (name, key, f)
+        rm = np.frombuffer(mats.tobytes(), dtype=dt["material"])
+        assert np.array_equal(rm["type"], t["materials"]["type"])
+        for i, ty in enumerate(rm["type"]):
+            if ty in (0, 1):
+                assert np.array_equal(rm["albedo"][i], t["materials"]["albedo"][i])
+            if ty == 1:
+                assert rm["fuzz"][i] == t["materials"]["fuzz"][i]
+            if ty == 2:
+                assert rm["ref_idx"][i] == t["materials"]["ref_idx"][i]
