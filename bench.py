@@ -40,6 +40,9 @@ def cpu_baseline():
     ref = os.path.join(ROOT, "oracle", "_ref")
     rrto, rrtc = os.path.join(ref, "rrto"), os.path.join(ref, "rrtc")
 
+    share = max(1, min(os.cpu_count() or 1, 16))  # one GPU's share of the host (16 cores on the MI355X boxes)
+    omp_env = dict(os.environ, OMP_NUM_THREADS=str(share))
+
     def run(exe, args, env=None):
         t = time.time()
         p = subprocess.run([exe, "-i", SCENE] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=600)
@@ -55,11 +58,11 @@ def cpu_baseline():
 
     if os.path.exists(rrto) and os.path.exists(rrtc):
         w, h, s = 1200, 800, 10
-        sec, threads = run(rrto, ["-w", str(w), "-h", str(h), "-s", str(s)])  # the reference's default (CPU BVH on)
-        out = {"value": round(w * h * s / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(threads) if threads and threads.isdigit() else os.cpu_count(), "kind": "reference",
+        sec, threads = run(rrto, ["-w", str(w), "-h", str(h), "-s", str(s)], env=omp_env)  # the reference's default (CPU BVH on)
+        out = {"value": round(w * h * s / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(threads) if threads and threads.isdigit() else share, "kind": "reference",
                "sample": "oracle/_ref/rrto (reference OpenMP fp64 build, its default CPU BVH) on scenes/final.txt %dx%d spp=%d d=50: %.2f s" % (w, h, s, sec)}
         w2, h2, s2 = 600, 400, 4
-        sec_b, _ = run(rrto, ["-w", str(w2), "-h", str(h2), "-s", str(s2), "-b"])
+        sec_b, _ = run(rrto, ["-w", str(w2), "-h", str(h2), "-s", str(s2), "-b"], env=omp_env)
         out["brute_force_value"] = round(w2 * h2 * s2 / sec_b / 1e6, 4)
         out["brute_force_sample"] = "rrto -b (list scan, the mode the HIP kernel implements) %dx%d spp=%d: %.2f s" % (w2, h2, s2, sec_b)
         sec_c, _ = run(rrtc, ["-w", str(w2), "-h", str(h2), "-s", str(s2)])

@@ -181,10 +181,13 @@ int rrtx_render(rrtx_ctx *ctx, void *fb, rrtx_stats *stats);
 
 /* Same render, output left in device memory: `d_rows` is a device pointer to
  * rrtx_shard_rows()*image_width*3 FP_T, local row k = k-th row of rrtx_shard_rows().
- * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous: returns
+ * `hip_stream` is a hipStream_t and is used as given (NULL = HIP's null stream, as in every HIP
+ * call; rrtx_stream() returns the context's own non-blocking stream).  Asynchronous: returns
  * after enqueueing; the framebuffer is complete when the stream reaches this point.  This is
  * the entry point the multi-GPU gather and bench.py use (inputs resident in HBM). */
 int rrtx_render_device(rrtx_ctx *ctx, void *d_rows, void *hip_stream);
+/* The context's own stream (hipStream_t), the one rrtx_render() launches on. */
+void *rrtx_stream(rrtx_ctx *ctx);
 
 /* Waits for the renders enqueued so far and fills `stats` for the last one. */
 int rrtx_collect(rrtx_ctx *ctx, rrtx_stats *stats);

@@ -15,6 +15,17 @@ if not os.path.exists(LIB_PATH):
         "rrt_amd: %s is missing - build it with `make` (or __graft_entry__.build()); this package has no fallback path" % LIB_PATH
     )
 
+# PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process do
+# not coexist ("No HIP GPUs are available" from whichever initialises second), so when torch is
+# installed load it FIRST: librrtx.so's NEEDED libamdhip64.so.7 then binds to the copy torch already
+# mapped and the whole process shares one runtime (and one set of streams, which is what lets
+# rrtx_render_device() launch on torch's current stream).  Without torch (the rrt / rrtd binaries,
+# plain ctypes users) the system ROCm runtime is used.
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:  # torch absent or broken: fall through to the system runtime
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 
@@ -110,6 +121,7 @@ _sig("rrtx_shard_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int])
 _sig("rrtx_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)])
 _sig("rrtx_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p])
 _sig("rrtx_collect", C.c_int, [C.c_void_p, C.POINTER(Stats)])
+_sig("rrtx_stream", C.c_void_p, [C.c_void_p])
 _sig("rrtx_scene_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)])
 _sig("rrtx_scene_exit_code", C.c_int, [])
 _sig("rrtx_scene_free", None, [C.c_void_p])

@@ -439,7 +439,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     if (!c || !d_rows) return fail(RRTX_E_INVALID, "rrtx_render_device: null argument");
     if (!c->have_scene) return fail(RRTX_E_NO_SCENE, "rrtx_render_device: no scene set");
     RRTX_HIP(hipSetDevice(c->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t st = (hipStream_t)hip_stream; // NULL is HIP's null stream, as everywhere in the HIP API
     if (c->ev_pending == kEventRing) {
         int rc = drain_events(c, nullptr);
         if (rc) return rc;
@@ -466,6 +466,8 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     c->ev_pending = slot + 1;
     return RRTX_OK;
 }
+
+void *rrtx_stream(rrtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
 {
@@ -511,7 +513,7 @@ int rrtx_render(rrtx_ctx *c, void *fb, rrtx_stats *stats)
     if (!c->d_rows && bytes) RRTX_HIP(hipMalloc(&c->d_rows, bytes));
     auto t0 = std::chrono::steady_clock::now();
     if (bytes) {
-        int rc = rrtx_render_device(c, c->d_rows, nullptr);
+        int rc = rrtx_render_device(c, c->d_rows, (void *)c->stream);
         if (rc) return rc;
     }
     RRTX_HIP(hipStreamSynchronize(c->stream));

@@ -155,10 +155,16 @@ class Rrt:
         self.stats = st.as_dict()
         return fb
 
-    def render_device(self, device_ptr, stream_ptr=None):
+    def render_device(self, device_ptr, stream_ptr=0):
         """Enqueue one render into device memory (local rows, compact).  `device_ptr` / `stream_ptr`
-        are raw addresses, e.g. tensor.data_ptr() and torch.cuda.current_stream().cuda_stream."""
-        check(lib.rrtx_render_device(self._ctx, C.c_void_p(int(device_ptr)), C.c_void_p(int(stream_ptr)) if stream_ptr else None), "rrtx_render_device")
+        are raw addresses, e.g. tensor.data_ptr() and torch.cuda.current_stream().cuda_stream
+        (0 = HIP's null stream, which is also torch's default stream)."""
+        check(lib.rrtx_render_device(self._ctx, C.c_void_p(int(device_ptr)), C.c_void_p(int(stream_ptr))), "rrtx_render_device")
+
+    @property
+    def stream(self):
+        """The context's own hipStream_t (used by render())."""
+        return lib.rrtx_stream(self._ctx) or 0
 
     def collect(self):
         st = _lib.Stats()

@@ -177,19 +177,23 @@ def test_exact_ties_resolve_like_the_sequential_scan(gpu, tmp_path):
 
 
 def test_statistical_agreement_with_the_real_rrtc(gpu):
-    """L3: the real rrtc binary uses its own mt19937 stream, so only statistics can
-    agree.  Fixtures: rrtc 60x40 at 1024 (512) spp.  Tolerances (8-bit LSB): mean signed difference
-    per channel < 0.25; RMS difference < 2.5 (rrtc-vs-rrtc at these spp measures 1.0-1.5);
-    8x8 block means within 1.0."""
+    """L3: the real rrtc binary draws from its own mt19937 stream, so only statistics
+    can agree.  Fixtures: rrtc 60x40 at 1024 (512) spp.  Tolerances in 8-bit LSB, calibrated with the
+    oracle (two independent seeds of OUR generator against each other, and against these fixtures,
+    measure: |mean signed difference| <= 0.04, RMS 1.0-1.55, largest 8x8-block mean 0.33-0.86
+    self / 0.42-1.17 vs rrtc, the latter being 2 sigma of the noisiest block):
+        |mean signed difference per channel| < 0.1
+        RMS difference < 1.8
+        every 8x8 block mean within 1.5"""
     for name, spp in (("test1", 1024), ("final", 1024), ("test2", 512), ("test3", 512)):
         ref = np.load(os.path.join(GOLDEN, "rrtc_%s_60x40_s%d.npy" % (name, spp))).astype(np.float64)
         fb, _ = _render(gpu, SCENES[name], 60, 40, spp)
         img = gpu.quantise(fb, spp).astype(np.float64)
         d = img - ref
-        assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.25), (name, d.mean(axis=(0, 1)))
-        assert np.sqrt((d ** 2).mean()) < 2.5, (name, np.sqrt((d ** 2).mean()))
+        assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.1), (name, d.mean(axis=(0, 1)))
+        assert np.sqrt((d ** 2).mean()) < 1.8, (name, np.sqrt((d ** 2).mean()))
         blocks = d[:40, :56].reshape(5, 8, 7, 8, 3).mean(axis=(1, 3))
-        assert np.abs(blocks).max() < 1.0, (name, np.abs(blocks).max())
+        assert np.abs(blocks).max() < 1.5, (name, np.abs(blocks).max())
 
 
 # ---- BASELINE.json full sizes: size-independent properties + spot rows against the oracle ----------
