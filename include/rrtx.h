@@ -116,8 +116,19 @@ typedef struct rrtx_params {
      * frame.  The image is bit-identical for every (shard_count, tile_rows).               */
     int32_t shard_rank, shard_count, tile_rows;
     int32_t collect_stats;             /* 1: count segments / primitive tests on the device  */
-    int32_t reserved[3];
+    int32_t flags;                     /* RRTX_FLAG_* bits                                   */
+    int32_t reserved[2];
 } rrtx_params;
+
+/* Scan every sphere with the reference's own discriminant (18 VALU ops per test) instead of the
+ * conservative 8-op FMA filter + exact refinement.  Both produce bit-identical images; the flag
+ * exists for A/B measurements and is forced internally for scenes whose magnitudes fall outside
+ * the filter's proven range. */
+#define RRTX_FLAG_EXACT_SCAN 1
+/* Where the scan reads sphere records from (A/B switches; default = alternate between scalar
+ * loads and an LDS copy whenever the table fits in LDS). */
+#define RRTX_FLAG_SCAN_SCALAR_ONLY 2
+#define RRTX_FLAG_SCAN_LDS_ONLY 4
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
@@ -134,6 +145,9 @@ typedef struct rrtx_stats {
     int32_t grid_blocks, block_threads;
     int32_t sample_chunk;    /* the value actually used                                      */
     int32_t local_rows;      /* rows rendered by this shard                                  */
+    uint64_t candidates;     /* (ray, primitive) pairs that reached the exact refinement      */
+    int32_t scan_filter;     /* 1 if the conservative scan filter was used                    */
+    int32_t reserved1;
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

@@ -46,7 +46,8 @@ class Params(C.Structure):  # rrtx_params
         ("shard_count", C.c_int32),
         ("tile_rows", C.c_int32),
         ("collect_stats", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -65,6 +66,9 @@ class Stats(C.Structure):  # rrtx_stats
         ("block_threads", C.c_int32),
         ("sample_chunk", C.c_int32),
         ("local_rows", C.c_int32),
+        ("candidates", C.c_uint64),
+        ("scan_filter", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
     def as_dict(self):
@@ -130,6 +134,9 @@ _sig("rrtx_scene_counts", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])
 _sig("rrtx_quantise", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p])
 _sig("rrtx_write_ppm", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int])
 _sig("rrtx_write_png", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int])
+
+
+FLAG_EXACT_SCAN = 1
 
 
 class RrtxError(RuntimeError):

@@ -71,7 +71,9 @@ struct rrtx_ctx {
     // scene
     bool have_scene = false;
     int n_sph = 0, n_sph_padded = 0, n_msph = 0, n_tri = 0, n_mat = 0;
-    void *d_hot = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_mat = nullptr;
+    void *d_hot = nullptr, *d_filter = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_mat = nullptr;
+    bool use_filter = false; // conservative scan filter valid for the current scene and not disabled
+    int lds_mode = 0;        // 0 scalar loads, 1 alternate scalar / LDS, 2 LDS only
     unsigned char cam_bytes[sizeof(CameraRec<double>)];
     // work buffers
     uint32_t *d_queue = nullptr;
@@ -148,7 +150,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     auto check_mat = [&](int idx) { return idx >= 0 && idx < s->num_materials; };
 
     // spheres: hot {center, r*r} + cold {r, material}; padded with never-hit records
-    const int pad = kSphereUnroll;
+    const int pad = kSpherePad;
     const int n_pad = ((s->num_spheres + pad - 1) / pad) * pad;
     std::vector<SphereHot<F>> hhot(n_pad > 0 ? n_pad : 1);
     std::vector<SphereCold<F>> hcold(n_pad > 0 ? n_pad : 1);
@@ -167,6 +169,31 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             hhot[i].r2 = -std::numeric_limits<F>::infinity();
             hcold[i].radius = 1;
             hcold[i].mat = 0;
+        }
+    }
+    // Conservative scan filter table {c, thr}: thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), evaluated in
+    // double (long double for fp64) and rounded DOWN, so the device-side test can only err towards
+    // "candidate".  The filter's error bound assumes finite, not absurdly scaled magnitudes; scenes
+    // outside that range use the exact scan.
+    std::vector<SphereHot<F>> hfil(n_pad > 0 ? n_pad : 1);
+    bool filter_ok = true;
+    {
+        const long double eps = sizeof(F) == 4 ? 0x1p-24L : 0x1p-53L;
+        const long double big = sizeof(F) == 4 ? 1e30L : 1e280L, tiny = sizeof(F) == 4 ? 1e-25L : 1e-250L;
+        for (int i = 0; i < n_pad; ++i) {
+            hfil[i].cx = hhot[i].cx, hfil[i].cy = hhot[i].cy, hfil[i].cz = hhot[i].cz;
+            if (i >= s->num_spheres) {
+                hfil[i].r2 = std::numeric_limits<F>::infinity(); // finite test values are always below it
+                continue;
+            }
+            const long double cx = hhot[i].cx, cy = hhot[i].cy, cz = hhot[i].cz, r2 = hhot[i].r2;
+            const long double c2 = cx * cx + cy * cy + cz * cz;
+            if (!(std::isfinite((double)c2) && std::isfinite((double)r2)) || !(c2 + r2 <= big) || !(c2 + r2 >= tiny)) filter_ok = false;
+            const long double thr = (c2 - r2) - (long double)kFilterK * eps * (c2 + r2);
+            F t = (F)thr;
+            if ((long double)t > thr) t = std::nextafter(t, -std::numeric_limits<F>::infinity());
+            t = std::nextafter(t, -std::numeric_limits<F>::infinity()); // one more ulp of slack
+            hfil[i].r2 = t;
         }
     }
     std::vector<MovingSphereRec<F>> hms(s->num_moving_spheres > 0 ? s->num_moving_spheres : 1);
@@ -209,10 +236,10 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     }
 
     RRTX_HIP(hipSetDevice(c->device));
-    void *old[5] = {c->d_hot, c->d_cold, c->d_msph, c->d_tri, c->d_mat};
+    void *old[6] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat};
     for (void *p : old)
         if (p) (void)hipFree(p);
-    c->d_hot = c->d_cold = c->d_msph = c->d_tri = c->d_mat = nullptr;
+    c->d_hot = c->d_filter = c->d_cold = c->d_msph = c->d_tri = c->d_mat = nullptr;
     c->have_scene = false;
 
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -222,6 +249,11 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     };
     int rc;
     if ((rc = up(&c->d_hot, hhot.data(), hhot.size() * sizeof(SphereHot<F>)))) return rc;
+    if ((rc = up(&c->d_filter, hfil.data(), hfil.size() * sizeof(SphereHot<F>)))) return rc;
+    c->use_filter = filter_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN);
+    c->lds_mode = 0;
+    if (c->use_filter && hfil.size() * sizeof(SphereHot<F>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
+        c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : (sizeof(F) == 8 ? 0 : 1); // fp64 is VALU-bound on scalar loads alone (measured)
     if ((rc = up(&c->d_cold, hcold.data(), hcold.size() * sizeof(SphereCold<F>)))) return rc;
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
@@ -239,6 +271,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
 {
     KernelParams<F> P = {};
     P.sph_hot = (const SphereHot<F> *)c->d_hot;
+    P.sph_filter = (const SphereHot<F> *)c->d_filter;
     P.sph_cold = (const SphereCold<F> *)c->d_cold;
     P.msph = (const MovingSphereRec<F> *)c->d_msph;
     P.tri = (const TriangleRec<F> *)c->d_tri;
@@ -373,8 +406,6 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
         e = hipEventCreate(&c->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&c->ev_stop[i]);
     }
-    int bpc = 0;
-    if (e == hipSuccess) e = p.fp64 ? render_occupancy<double>(&bpc) : render_occupancy<float>(&bpc);
     if (e != hipSuccess) {
         char buf[256];
         snprintf(buf, sizeof buf, "rrtx_create: HIP error = %u (%s)", (unsigned)e, hipGetErrorString(e));
@@ -382,14 +413,7 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
         return fail(RRTX_E_DEVICE, buf);
     }
     c->num_cus = prop.multiProcessorCount;
-    c->blocks_per_cu = bpc < 1 ? 1 : bpc;
-    // persistent grid: fill the chip once; never more blocks than there are task batches
-    int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
-    const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
-    const int64_t need_blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (grid > need_blocks) grid = need_blocks;
-    if (grid < 1) grid = 1;
-    c->grid_blocks = (int)grid;
+    c->grid_blocks = 1;
     *out = c;
     return RRTX_OK;
 }
@@ -399,7 +423,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_hot, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -421,7 +445,20 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         return fail(RRTX_E_INVALID, "rrtx_set_scene: count without table");
     if ((int64_t)s->num_spheres + s->num_moving_spheres + s->num_triangles > (1 << 28)) return fail(RRTX_E_INVALID, "rrtx_set_scene: too many primitives");
     if (c->stream) RRTX_HIP(hipStreamSynchronize(c->stream));
-    return c->p.fp64 ? upload_scene<double>(c, s) : upload_scene<float>(c, s);
+    int rc = c->p.fp64 ? upload_scene<double>(c, s) : upload_scene<float>(c, s);
+    if (rc) return rc;
+    // persistent grid: fill the chip once with the kernel variant this scene selects; never more
+    // blocks than there are task batches
+    int bpc = 0;
+    RRTX_HIP(c->p.fp64 ? render_occupancy<double>(c->use_filter, c->lds_mode, c->n_sph_padded, &bpc) : render_occupancy<float>(c->use_filter, c->lds_mode, c->n_sph_padded, &bpc));
+    c->blocks_per_cu = bpc < 1 ? 1 : bpc;
+    int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
+    const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
+    const int64_t need_blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    c->grid_blocks = (int)grid;
+    return RRTX_OK;
 }
 
 int rrtx_shard_rows(const rrtx_ctx *c, int32_t *rows, int cap)
@@ -446,19 +483,19 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     }
     if (c->total_tasks == 0) return RRTX_OK;
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 4, st));
-    if (c->p.collect_stats) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 8, st));
+    if (c->p.collect_stats) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 16, st));
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->chunks_per_pixel > 1 ? c->d_partial : d_rows;
     if (c->p.fp64) {
         KernelParams<double> P = make_params<double>(c, out);
-        RRTX_HIP(launch_render<double>(P, c->grid_blocks, st));
+        RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
         if (c->chunks_per_pixel > 1)
             RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
     }
     else {
         KernelParams<float> P = make_params<float>(c, out);
-        RRTX_HIP(launch_render<float>(P, c->grid_blocks, st));
+        RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
         if (c->chunks_per_pixel > 1)
             RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
     }
@@ -486,9 +523,11 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
         if (c->p.collect_stats) {
-            unsigned long long seg = 0;
-            RRTX_HIP(hipMemcpy(&seg, c->d_counters, sizeof seg, hipMemcpyDeviceToHost));
+            unsigned long long ctr[2] = {0, 0};
+            RRTX_HIP(hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
+            const unsigned long long seg = ctr[0];
             stats->segments = seg;
+            stats->candidates = ctr[1];
             const uint64_t nprim = (uint64_t)c->n_sph + c->n_msph + c->n_tri;
             stats->prim_tests = seg * nprim;
             // B_prim = 4 scalars (sphere) / 9 scalars (moving sphere, triangle)
@@ -499,6 +538,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->block_threads = kBlockThreads;
         stats->sample_chunk = c->chunk;
         stats->local_rows = c->local_rows;
+        stats->scan_filter = c->use_filter ? 1 : 0;
     }
     return RRTX_OK;
 }

@@ -18,11 +18,16 @@
 
 namespace rrtx {
 
-constexpr int kSphereUnroll = 8;  // sphere table is padded to a multiple of this
+constexpr int kSphereUnroll = 8;  // tests per straight-line block (fp32; fp64 uses half)
+constexpr int kSpherePad = 16;    // the sphere tables are padded to a multiple of this (two blocks)
+constexpr int kLdsSceneBytes = 48 * 1024; // largest scan table mirrored in LDS
 constexpr int kCandCap = 16;      // candidate slots per lane (LDS), flushed when nearly full
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr uint32_t kTaskBatch = 64; // tasks a wave pulls from the global queue at a time
+// Safety factor of the conservative scan filter, in units of the unit roundoff.  The
+// analytic bound needs about 160; empirically false negatives appear only below 16.
+constexpr int kFilterK = 256;
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
     F cx, cy, cz, r2;
@@ -58,7 +63,8 @@ template <typename F> struct CameraRec { // camera.h:43-48
 };
 
 template <typename F> struct KernelParams {
-    const SphereHot<F> *sph_hot; // n_sph_padded records
+    const SphereHot<F> *sph_hot;    // n_sph_padded records {cx, cy, cz, r*r}: the exact test
+    const SphereHot<F> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter
     const SphereCold<F> *sph_cold;
     const MovingSphereRec<F> *msph;
     const TriangleRec<F> *tri;
@@ -74,7 +80,7 @@ template <typename F> struct KernelParams {
     uint32_t total_tasks;    // local_rows * W * chunks_per_pixel
     uint32_t *queue;         // global task cursor (zeroed before every launch)
     F *out;                  // [total_tasks][3]: per-task partial sums (== the local frame when chunks_per_pixel == 1)
-    unsigned long long *counters; // [0] segments (only if collect_stats)
+    unsigned long long *counters; // [0] segments, [1] candidates refined in phase 2 (only if collect_stats)
     int32_t collect_stats;
 };
 

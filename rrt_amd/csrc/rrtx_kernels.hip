@@ -57,6 +57,9 @@ RRTX_DEV double ffabs(double x) { return __builtin_fabs(x); }
 RRTX_DEV float ffmin(float a, float b) { return __builtin_fminf(a, b); }
 RRTX_DEV double ffmin(double a, double b) { return __builtin_fmin(a, b); }
 template <typename F> RRTX_DEV V3<F> vunit(V3<F> v) { return vdiv<F>(v, fsqrt(vlen2(v))); } // vec3.h:125
+// explicit fused multiply-add: used ONLY by the conservative scan filter (never on the exact path)
+RRTX_DEV float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RRTX_DEV double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // POW(1-cosine, 5) of material.h:108.  rrtc calls powf(); x^5 formed in double from a float x is
 // exact up to 2 ulp(double) and rounds to the same float except within 2^-28 of a rounding
@@ -73,6 +76,9 @@ RRTX_DEV double pow5(double x)
     return x2 * x2 * x;
 }
 
+template <int N> struct IntC {
+    static constexpr int value = N;
+};
 template <typename F> struct SphereUnroll;
 template <> struct SphereUnroll<float> {
     static constexpr int value = kSphereUnroll; // 8 x 16 B = 32 SGPRs per block
@@ -83,9 +89,15 @@ template <> struct SphereUnroll<double> {
 template <typename F> struct Limits;
 template <> struct Limits<float> {
     static RRTX_DEV float inf() { return __builtin_huge_valf(); }
+    static RRTX_DEV float margin() { return (float)kFilterK * 0x1p-24f; } // K * unit roundoff
+    static RRTX_DEV float big() { return 1e30f; }
+    static RRTX_DEV float tiny() { return 1e-30f; }
 };
 template <> struct Limits<double> {
     static RRTX_DEV double inf() { return __builtin_huge_val(); }
+    static RRTX_DEV double margin() { return (double)kFilterK * 0x1p-53; }
+    static RRTX_DEV double big() { return 1e280; }
+    static RRTX_DEV double tiny() { return 1e-280; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -143,6 +155,80 @@ template <typename F> RRTX_DEV V3<F> in_unit_sphere(Rng &r)
         p.z = rng_range<F>(r, (F)-1, (F)1);
     } while (vlen2(p) >= 1);
     return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate push.  `test < thr` false (or unordered) => append primitive index `k0 + u` to this
+// lane's list.  Hand-scheduled because the compiler's lowering of "if (cand) push" costs three
+// scalar instructions per test (s_and_saveexec / s_cbranch_execz / s_or exec) on the path where NO
+// lane is a candidate — 78 % of the tests on final.txt — and once the test itself is down to 8 VALU
+// instructions those scalar slots limit the wave.  Here that path is ONE scalar branch.
+//   v_cmp_ngt  vcc = !(thr > value)            (true for NaN, like the reference's !(disc < 0))
+//   s_cbranch_vccz skip                        wave-uniform: nobody is a candidate
+//   s_and_saveexec  /  ds_write_b32 list[cnt] = k0 + u ; cnt += 1  /  restore exec
+// LDS ops of one wave execute in order, so the later ds_read of the drain sees these writes; the
+// extra lgkmcnt they hold only makes compiler-placed waits more conservative.
+// ---------------------------------------------------------------------------------------------
+#ifndef RRTX_ASM_PUSH
+#define RRTX_ASM_PUSH 1
+#endif
+
+#ifdef RRTX_EXPERIMENT // timing experiments only (wrong images): 1 = compare only, 2 = compare + branch, no push
+#if RRTX_EXPERIMENT == 1
+#define RRTX_PUSH_ASM(CMP, THRC) asm volatile(CMP " vcc, %[thr], %[val]" : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save) : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U) : "vcc", "scc", "memory")
+#else
+#define RRTX_PUSH_ASM(CMP, THRC) asm volatile(CMP " vcc, %[thr], %[val]\n\ts_cbranch_vccz 1f\n\ts_nop 0\n1:" : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save) : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U) : "vcc", "scc", "memory")
+#endif
+#else
+#define RRTX_PUSH_ASM(CMP, THRC)                                                                                       \
+    asm volatile(CMP " vcc, %[thr], %[val]\n\t"                                                                        \
+                     "s_cbranch_vccz 1f\n\t"                                                                           \
+                     "s_and_saveexec_b64 %[save], vcc\n\t"                                                             \
+                     "v_lshl_add_u32 %[addr], %[cnt], 8, %[base]\n\t"                                                  \
+                     "v_mov_b32 %[tmp], %[k0]\n\t"                                                                     \
+                     "v_add_u32 %[tmp], %[u], %[tmp]\n\t"                                                              \
+                     "ds_write_b32 %[addr], %[tmp]\n\t"                                                                \
+                     "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                                 \
+                     "s_mov_b64 exec, %[save]\n"                                                                        \
+                     "1:"                                                                                               \
+                 : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save)                            \
+                 : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U)               \
+                 : "vcc", "scc", "memory")
+#endif
+
+// lane_lds_addr = LDS byte address of this lane's slot 0; slot s is 256 bytes further (64 lanes x 4 B).
+// THR_IN_VGPR: the threshold came from LDS (vector register) instead of a scalar load.
+template <int U, bool THR_IN_VGPR> RRTX_DEV void push_if_not_less(float value, float thr, uint32_t &cnt, uint32_t lane_lds_addr, uint32_t *my_cand, int k0)
+{
+#if RRTX_ASM_PUSH
+    uint32_t addr, tmp;
+    uint64_t save;
+    if (THR_IN_VGPR)
+        RRTX_PUSH_ASM("v_cmp_ngt_f32", "v");
+    else
+        RRTX_PUSH_ASM("v_cmp_ngt_f32", "s");
+#else
+    if (!(value < thr)) {
+        my_cand[cnt * 64] = (uint32_t)(k0 + U);
+        cnt += 1;
+    }
+#endif
+}
+template <int U, bool THR_IN_VGPR> RRTX_DEV void push_if_not_less(double value, double thr, uint32_t &cnt, uint32_t lane_lds_addr, uint32_t *my_cand, int k0)
+{
+#if RRTX_ASM_PUSH
+    uint32_t addr, tmp;
+    uint64_t save;
+    if (THR_IN_VGPR)
+        RRTX_PUSH_ASM("v_cmp_ngt_f64", "v");
+    else
+        RRTX_PUSH_ASM("v_cmp_ngt_f64", "s");
+#else
+    if (!(value < thr)) {
+        my_cand[cnt * 64] = (uint32_t)(k0 + U);
+        cnt += 1;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,16 +297,28 @@ template <typename F, bool FULL> RRTX_DEV bool triangle_test(const TriangleRec<F
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
+// LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
+// between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
+// scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
+template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
 {
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCandCap][64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records
+    SphereHot<F> *const sph_lds = (SphereHot<F> *)dyn_lds;
+    if (LDSMODE != 0) {
+        const SphereHot<F> *src = FILTER ? P.sph_filter : P.sph_hot;
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) sph_lds[i] = src[i];
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *const my_cand = &cand_lds[wave][0][lane]; // slot s at my_cand[s * 64]: bank == lane, conflict-free
+    const uint32_t my_cand_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)my_cand; // LDS byte address
+    const F zero_sgpr = (F)0;
 
     typedef const RRTX_CONST_AS SphereHot<F> *HotPtr; // constant address space => s_load for uniform indices
-    const HotPtr sph_scalar = (HotPtr)P.sph_hot;
+    const HotPtr sph_scalar = (HotPtr)(FILTER ? P.sph_filter : P.sph_hot);
 
     const F t_min = (F)0.001; // rrt.cpp:32 typing
     const int n_sph = P.n_sph, n_sph_pad = P.n_sph_padded, n_msph = P.n_msph, n_tri = P.n_tri;
@@ -240,7 +338,7 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_ke
     path.tm = 0;
     path.depth = 0;
     Rng rng = {0, 0, 0};
-    uint32_t n_segments = 0;
+    uint32_t n_segments = 0, n_candidates = 0;
 
     for (;;) {
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
@@ -323,6 +421,7 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_ke
 
             // phase 2 body, used for flushes and at the end
             auto drain = [&]() {
+                n_candidates += cnt;
                 for (uint32_t s = 0; s < cnt; ++s) {
                     const int k = (int)my_cand[s * 64];
                     if (k < msph_base) {
@@ -348,33 +447,79 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_ke
             };
 
             // phase 1a: spheres, wave-uniform scalar loads.  The block of kUnroll tests is kept
-            // branch-free (all discriminants first, pushes afterwards) so that the scalar loads of a
-            // whole block are issued together and the VALU stream is one straight line.
+            // branch-free (all tests first, pushes afterwards) so that the scalar loads of a whole
+            // block are issued together and the VALU stream is one straight line.
+            //
+            // FILTER = false: the reference's discriminant itself (sphere.h:35-40), 17 VALU + 1 compare.
+            // FILTER = true : a CONSERVATIVE test in 7 FMAs + 1 compare that can only err towards
+            //   "candidate" (DESIGN.md "Conservative scan filter" has the bound).  With n = d/|d|,
+            //   u = c.n, s = o.n:   disc/|d|^2 = u^2 + 2(o - s n).c + (s^2 - |o|^2) + (r^2 - |c|^2).
+            //   Per segment: n, b = 2(o - s n), g = s^2 - |o|^2 + K eps |o|^2.  Per sphere (SGPRs):
+            //   c and thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), rounded down on the host.
+            //   candidate  <=>  not (u^2 + b.c + g < thr).   Phase 2 then applies the exact test.
+            F nx = 0, ny = 0, nz = 0, bx = 0, by = 0, bz = 0, g = Limits<F>::inf();
+            if (FILTER) {
+                const F o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
+                // rays with non-finite or extreme components take the always-candidate route (g = +inf):
+                // phase 2 is exact, so they stay correct, merely slow
+                if (a >= Limits<F>::tiny() && a <= Limits<F>::big() && o2 <= Limits<F>::big()) {
+                    const F inv = (F)1 / fsqrt(a);
+                    nx = path.d.x * inv, ny = path.d.y * inv, nz = path.d.z * inv;
+                    const F sdot = ffma(path.o.z, nz, ffma(path.o.y, ny, path.o.x * nx));
+                    bx = (F)2 * ffma(-sdot, nx, path.o.x);
+                    by = (F)2 * ffma(-sdot, ny, path.o.y);
+                    bz = (F)2 * ffma(-sdot, nz, path.o.z);
+                    g = ffma(Limits<F>::margin(), o2, ffma(sdot, sdot, -o2));
+                }
+            }
             constexpr int kUnroll = SphereUnroll<F>::value;
-            for (int k0 = 0; k0 < n_sph_pad; k0 += kUnroll) {
+            // one block of kUnroll tests; FROM_LDS selects the operand source
+            auto scan_block = [&](int k0, auto from_lds_c) {
+                constexpr bool FROM_LDS = decltype(from_lds_c)::value != 0;
                 if (__ballot(cnt > (uint32_t)(kCandCap - kUnroll)) != 0ull) drain();
-                bool is_cand[kUnroll];
-                uint64_t any_cand = 0ull; // OR of the compare masks: scalar ALU only
+                // the block's records first (two s_load_dwordx16, or kUnroll ds_read_b128 broadcasts),
+                // then kUnroll x {test, push}
+                F bcx[kUnroll], bcy[kUnroll], bcz[kUnroll], bw[kUnroll];
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    const int k = k0 + u;
-                    const F cx = sph_scalar[k].cx, cy = sph_scalar[k].cy, cz = sph_scalar[k].cz, r2 = sph_scalar[k].r2;
-                    const F ocx = path.o.x - cx, ocy = path.o.y - cy, ocz = path.o.z - cz;
-                    const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;
-                    const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
-                    const F disc = half_b * half_b - a * c;
-                    is_cand[u] = !(disc < 0);
-                    any_cand |= __ballot(is_cand[u]);
-                }
-                if (any_cand != 0ull) {
-#pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
-                        if (is_cand[u]) {
-                            my_cand[cnt * 64] = (uint32_t)(k0 + u);
-                            cnt += 1;
-                        }
+                    if (FROM_LDS) {
+                        const SphereHot<F> r = sph_lds[k0 + u];
+                        bcx[u] = r.cx, bcy[u] = r.cy, bcz[u] = r.cz, bw[u] = r.r2;
+                    }
+                    else {
+                        bcx[u] = sph_scalar[k0 + u].cx, bcy[u] = sph_scalar[k0 + u].cy, bcz[u] = sph_scalar[k0 + u].cz, bw[u] = sph_scalar[k0 + u].r2;
                     }
                 }
+                auto test = [&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const F cx = bcx[u], cy = bcy[u], cz = bcz[u], r2 = bw[u];
+                    if (FILTER) {
+                        const F uu = ffma(cz, nz, ffma(cy, ny, cx * nx));
+                        const F w = ffma(bz, cz, ffma(by, cy, ffma(bx, cx, g)));
+                        push_if_not_less<u, FROM_LDS>(ffma(uu, uu, w), r2, cnt, my_cand_lds, my_cand, k0); // the r2 slot holds thr
+                    }
+                    else {
+                        const F ocx = path.o.x - cx, ocy = path.o.y - cy, ocz = path.o.z - cz;
+                        const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;
+                        const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+                        const F disc = half_b * half_b - a * c;
+                        push_if_not_less<u, false>(disc, zero_sgpr, cnt, my_cand_lds, my_cand, k0); // !(disc < 0), sphere.h:41
+                    }
+                };
+                test(IntC<0>());
+                test(IntC<1>());
+                test(IntC<2>());
+                test(IntC<3>());
+                if (kUnroll > 4) {
+                    test(IntC<4 % kUnroll>());
+                    test(IntC<5 % kUnroll>());
+                    test(IntC<6 % kUnroll>());
+                    test(IntC<7 % kUnroll>());
+                }
+            };
+            for (int k0 = 0; k0 < n_sph_pad; k0 += 2 * kUnroll) { // the table is padded to 2 * kUnroll records
+                scan_block(k0, IntC<(LDSMODE == 2)>());
+                scan_block(k0 + kUnroll, IntC<(LDSMODE != 0)>());
             }
             // phase 1b: moving spheres (center depends on the ray's time: per-lane)
             for (int m = 0; m < n_msph; ++m) {
@@ -505,7 +650,10 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) render_ke
         }
     }
 
-    if (P.collect_stats) atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+    if (P.collect_stats) {
+        atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+        atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
+    }
 }
 
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
@@ -525,10 +673,20 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
-template <typename F> hipError_t launch_render(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
+template <typename F, bool FILTER, int LDSMODE> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(render_kernel<F>, dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
+}
+template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)
+{
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
+    if (!filter) return launch_variant<F, false, 0>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
+    switch (lds_mode) {
+    case 1: return launch_variant<F, true, 1>(P, grid_blocks, lds, stream);
+    case 2: return launch_variant<F, true, 2>(P, grid_blocks, lds, stream);
+    default: return launch_variant<F, true, 0>(P, grid_blocks, 0, stream);
+    }
 }
 template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32_t n_values, int chunks_per_pixel, hipStream_t stream)
 {
@@ -538,16 +696,22 @@ template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32
     hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, n_values, chunks_per_pixel);
     return hipGetLastError();
 }
-template <typename F> hipError_t render_occupancy(int *blocks_per_cu)
+template <typename F> hipError_t render_occupancy(bool filter, int lds_mode, int n_sph_padded, int *blocks_per_cu)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F>, kBlockThreads, 0);
+    const size_t lds = lds_mode ? (size_t)n_sph_padded * sizeof(SphereHot<F>) : 0;
+    if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0>, kBlockThreads, 0);
+    switch (lds_mode) {
+    case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1>, kBlockThreads, lds);
+    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2>, kBlockThreads, lds);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0>, kBlockThreads, 0);
+    }
 }
 
-template hipError_t launch_render<float>(const KernelParams<float> &, int, hipStream_t);
-template hipError_t launch_render<double>(const KernelParams<double> &, int, hipStream_t);
+template hipError_t launch_render<float>(const KernelParams<float> &, bool, int, int, hipStream_t);
+template hipError_t launch_render<double>(const KernelParams<double> &, bool, int, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, uint32_t, int, hipStream_t);
 template hipError_t launch_finalize<double>(const double *, double *, uint32_t, int, hipStream_t);
-template hipError_t render_occupancy<float>(int *);
-template hipError_t render_occupancy<double>(int *);
+template hipError_t render_occupancy<float>(bool, int, int, int *);
+template hipError_t render_occupancy<double>(bool, int, int, int *);
 
 } // namespace rrtx
