@@ -117,7 +117,10 @@ typedef struct rrtx_params {
     int32_t shard_rank, shard_count, tile_rows;
     int32_t collect_stats;             /* 1: count segments / primitive tests on the device  */
     int32_t flags;                     /* RRTX_FLAG_* bits                                   */
-    int32_t reserved[2];
+    int32_t handoff_lanes;             /* tuning: a wave parks its unfinished items for the tail
+                                          kernel once the queue is dry and at most this many of
+                                          its 64 lanes are alive; 0 = default (7)              */
+    int32_t reserved[1];               /* [0]: tuning, hand-off iteration cap (0 = default 8)   */
 } rrtx_params;
 
 /* Scan every sphere with the reference's own discriminant (18 VALU ops per test) instead of the
@@ -129,6 +132,9 @@ typedef struct rrtx_params {
  * loads and an LDS copy whenever the table fits in LDS). */
 #define RRTX_FLAG_SCAN_SCALAR_ONLY 2
 #define RRTX_FLAG_SCAN_LDS_ONLY 4
+/* Let the render kernel finish every path itself instead of handing the last few to the tail
+ * kernel (A/B switch; the images are identical). */
+#define RRTX_FLAG_NO_TAIL_KERNEL 8
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST

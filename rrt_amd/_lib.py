@@ -47,7 +47,8 @@ class Params(C.Structure):  # rrtx_params
         ("tile_rows", C.c_int32),
         ("collect_stats", C.c_int32),
         ("flags", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("handoff_lanes", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

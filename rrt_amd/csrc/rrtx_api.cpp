@@ -72,6 +72,7 @@ struct rrtx_ctx {
     bool have_scene = false;
     int n_sph = 0, n_sph_padded = 0, n_msph = 0, n_tri = 0, n_mat = 0;
     void *d_hot = nullptr, *d_filter = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_mat = nullptr;
+    bool tail_ok = false;    // scene magnitudes allow the tail kernel's split scan (no NaN roots possible)
     bool use_filter = false; // conservative scan filter valid for the current scene and not disabled
     int lds_mode = 0;        // 0 scalar loads, 1 alternate scalar / LDS, 2 LDS only
     unsigned char cam_bytes[sizeof(CameraRec<double>)];
@@ -79,6 +80,13 @@ struct rrtx_ctx {
     uint32_t *d_queue = nullptr;
     unsigned long long *d_counters = nullptr;
     void *d_partial = nullptr; // [total_tasks][3] when chunks_per_pixel > 1
+    void *d_tail_items = nullptr; // parked work items (render kernel -> tail kernel)
+#ifdef RRTX_DIAG
+    unsigned long long *d_diag = nullptr;
+#endif
+    size_t tail_capacity = 0;
+    int handoff_lanes = kHandoffLanes;
+    int tail_blocks = 0;
     void *d_rows = nullptr;    // own output buffer for the host-pointer API
     // timing
     hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
@@ -258,6 +266,22 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
     if ((rc = up(&c->d_mat, hmat.data(), hmat.size() * sizeof(MaterialRec<F>)))) return rc;
+    {
+        // the tail kernel's split scan needs every root to be non-NaN: finite primitives of bounded
+        // magnitude (so that no intermediate of the discriminant overflows)
+        const double lim = sizeof(F) == 4 ? 3e7 : 1e60;
+        bool ok = true;
+        auto chk = [&](double v) { ok = ok && std::isfinite(v) && std::fabs(v) <= lim; };
+        for (int i = 0; i < s->num_spheres; ++i) chk(hhot[i].cx), chk(hhot[i].cy), chk(hhot[i].cz), chk(hcold[i].radius);
+        for (int i = 0; i < s->num_moving_spheres; ++i) {
+            for (int k = 0; k < 3; ++k) chk(hms[i].c0[k]), chk(hms[i].dc[k]);
+            chk(hms[i].t0), chk(hms[i].dt), chk(hms[i].radius);
+            ok = ok && hms[i].dt != 0; // (time - t0) / 0 is where NaN centres come from
+        }
+        for (int i = 0; i < s->num_triangles; ++i)
+            for (int k = 0; k < 3; ++k) chk(htri[i].v0[k]), chk(htri[i].e1[k]), chk(htri[i].e2[k]), chk(htri[i].n[k]);
+        c->tail_ok = ok;
+    }
     c->n_sph = s->num_spheres;
     c->n_sph_padded = n_pad;
     c->n_msph = s->num_moving_spheres;
@@ -288,6 +312,14 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.out = (F *)out;
     P.counters = c->d_counters;
     P.collect_stats = c->p.collect_stats;
+    P.handoff_lanes = c->tail_capacity ? c->handoff_lanes : 0;
+    P.handoff_iters = c->p.reserved[0] > 0 ? c->p.reserved[0] : kHandoffIters;
+    P.tail_count = c->d_queue + 1;
+    P.tail_items = (TailItem<F> *)c->d_tail_items;
+    P.diag = nullptr;
+#ifdef RRTX_DIAG
+    P.diag = c->d_diag;
+#endif
     return P;
 }
 
@@ -402,6 +434,10 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_counters, 256);
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 256);
     if (e == hipSuccess && c->chunks_per_pixel > 1) e = hipMalloc(&c->d_partial, (size_t)c->total_tasks * 3 * c->fsize + 64);
+#ifdef RRTX_DIAG
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_diag, (size_t)131072 * 64);
+    if (e == hipSuccess) e = hipMemset(c->d_diag, 0, (size_t)131072 * 64);
+#endif
     for (int i = 0; i < kEventRing && e == hipSuccess; ++i) {
         e = hipEventCreate(&c->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&c->ev_stop[i]);
@@ -423,7 +459,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -458,6 +494,22 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
+    // parked-item buffer: every resident wave can park at most kHandoffLanes items
+    if (c->d_tail_items) {
+        (void)hipFree(c->d_tail_items);
+        c->d_tail_items = nullptr;
+    }
+    c->tail_capacity = 0;
+    if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
+        const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
+        c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
+        c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 64; // a wave may park all 64 lanes when the iteration cap fires
+        RRTX_HIP(hipMalloc(&c->d_tail_items, c->tail_capacity * item));
+        int64_t tb = (int64_t)(c->tail_capacity + kWavesPerBlock - 1) / kWavesPerBlock; // one wave per item at most
+        const int64_t cap = (int64_t)c->num_cus * 8;
+        c->tail_blocks = (int)(tb < cap ? tb : cap);
+        if (c->tail_blocks < 1) c->tail_blocks = 1;
+    }
     return RRTX_OK;
 }
 
@@ -482,7 +534,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
         if (rc) return rc;
     }
     if (c->total_tasks == 0) return RRTX_OK;
-    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 4, st));
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 12, st)); // task cursor, parked-item count, tail cursor
     if (c->p.collect_stats) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 16, st));
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
@@ -490,12 +542,14 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     if (c->p.fp64) {
         KernelParams<double> P = make_params<double>(c, out);
         RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(launch_tail<double>(P, c->tail_blocks, st));
         if (c->chunks_per_pixel > 1)
             RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
     }
     else {
         KernelParams<float> P = make_params<float>(c, out);
         RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(launch_tail<float>(P, c->tail_blocks, st));
         if (c->chunks_per_pixel > 1)
             RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
     }
@@ -505,6 +559,16 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
 }
 
 void *rrtx_stream(rrtx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+#ifdef RRTX_DIAG
+extern "C" int rrtx_diag_read(rrtx_ctx *c, void *dst)
+{
+    RRTX_HIP(hipDeviceSynchronize());
+    RRTX_HIP(hipMemcpy(dst, c->d_diag, (size_t)131072 * 64, hipMemcpyDeviceToHost));
+    RRTX_HIP(hipMemset(c->d_diag, 0, (size_t)131072 * 64));
+    return 0;
+}
+#endif
 
 int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
 {

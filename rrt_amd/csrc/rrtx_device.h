@@ -28,6 +28,10 @@ constexpr uint32_t kTaskBatch = 64; // tasks a wave pulls from the global queue 
 // Safety factor of the conservative scan filter, in units of the unit roundoff.  The
 // analytic bound needs about 160; empirically false negatives appear only below 16.
 constexpr int kFilterK = 256;
+// A wave of the render kernel hands its unfinished items to the tail kernel once the queue is dry and
+// at most this many of its lanes are alive (break-even of one-ray-per-wave against one-ray-per-lane).
+constexpr int kHandoffLanes = 7;
+constexpr int kHandoffIters = 8; // ... and after this many iterations past queue-dry regardless of the lane count
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
     F cx, cy, cz, r2;
@@ -62,6 +66,16 @@ template <typename F> struct CameraRec { // camera.h:43-48
     F lens_radius, time0, time1;
 };
 
+// A parked work item (render kernel -> tail kernel)
+template <typename F> struct TailItem {
+    uint32_t task;
+    int32_t s_cur, depth;
+    uint32_t need_ray;
+    uint32_t k0, k1, n, pad; // RNG stream of the current sample and its draw counter
+    F acc[3];                // partial sum of the task so far
+    F o[3], d[3], tm, atten[3];
+};
+
 template <typename F> struct KernelParams {
     const SphereHot<F> *sph_hot;    // n_sph_padded records {cx, cy, cz, r*r}: the exact test
     const SphereHot<F> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter
@@ -82,6 +96,11 @@ template <typename F> struct KernelParams {
     F *out;                  // [total_tasks][3]: per-task partial sums (== the local frame when chunks_per_pixel == 1)
     unsigned long long *counters; // [0] segments, [1] candidates refined in phase 2 (only if collect_stats)
     int32_t collect_stats;
+    int32_t handoff_lanes;   // 0 = never hand off (the render kernel finishes everything itself)
+    int32_t handoff_iters;   // ... and unconditionally this many iterations after the queue ran dry
+    uint32_t *tail_count;    // [0] number of parked items, [1] the tail kernel's cursor (zeroed before every launch)
+    TailItem<F> *tail_items; // capacity: resident waves * handoff_lanes
+    unsigned long long *diag; // RRTX_DIAG builds only (timing stamps), otherwise unused
 };
 
 } // namespace rrtx

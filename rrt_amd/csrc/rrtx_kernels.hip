@@ -92,12 +92,16 @@ template <> struct Limits<float> {
     static RRTX_DEV float margin() { return (float)kFilterK * 0x1p-24f; } // K * unit roundoff
     static RRTX_DEV float big() { return 1e30f; }
     static RRTX_DEV float tiny() { return 1e-30f; }
+    static RRTX_DEV float coop_big() { return 1e15f; }   // squares and products of these stay finite
+    static RRTX_DEV float coop_tiny() { return 1e-15f; }
 };
 template <> struct Limits<double> {
     static RRTX_DEV double inf() { return __builtin_huge_val(); }
     static RRTX_DEV double margin() { return (double)kFilterK * 0x1p-53; }
     static RRTX_DEV double big() { return 1e280; }
     static RRTX_DEV double tiny() { return 1e-280; }
+    static RRTX_DEV double coop_big() { return 1e120; }
+    static RRTX_DEV double coop_tiny() { return 1e-120; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -297,6 +301,131 @@ template <typename F, bool FULL> RRTX_DEV bool triangle_test(const TriangleRec<F
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Pieces shared by the render kernel (one ray per lane) and the tail kernel (one ray per wave)
+// ---------------------------------------------------------------------------------------------
+// task -> (pixel, first/last sample of its chunk)
+template <typename F> RRTX_DEV void task_decode(const KernelParams<F> &P, uint32_t task, int &px_i, int &px_j, int &s_first, int &s_end)
+{
+    const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
+    const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
+    const uint32_t lr = q / (uint32_t)P.W;
+    px_i = (int)(q - lr * (uint32_t)P.W);
+    const uint32_t tile = lr / (uint32_t)P.tile_rows;
+    px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
+    s_first = (int)c * P.chunk;
+    s_end = s_first + P.chunk < P.spp ? s_first + P.chunk : P.spp;
+}
+
+// camera ray of sample `s` of pixel (i, j): rrt.cu:112-114, camera.h:31-38
+template <typename F> RRTX_DEV void camera_ray(const KernelParams<F> &P, int px_i, int px_j, int s, Rng &rng, Path<F> &path)
+{
+    rng_open(rng, P.seed, (uint32_t)(px_j * P.W + px_i), (uint32_t)s);
+    const F u = ((F)px_i + rng_uniform<F>(rng)) / (F)(P.W - 1);
+    const F v = ((F)px_j + rng_uniform<F>(rng)) / (F)(P.H - 1);
+    F dx, dy;
+    do { // random_in_unit_disk, vec3.h:127-134
+        dx = rng_range<F>(rng, (F)-1, (F)1);
+        dy = rng_range<F>(rng, (F)-1, (F)1);
+    } while (dx * dx + dy * dy >= 1); // + 0*0 of the z component changes nothing
+    const F rdx = P.cam.lens_radius * dx, rdy = P.cam.lens_radius * dy;
+    const V3<F> offset = vadd<F>(vscale<F>(rdx, ld3<F>(P.cam.u)), vscale<F>(rdy, ld3<F>(P.cam.v)));
+    const V3<F> org = ld3<F>(P.cam.origin);
+    path.o = vadd<F>(org, offset);
+    path.d = vsub<F>(vsub<F>(vadd<F>(vadd<F>(ld3<F>(P.cam.llc), vscale<F>(u, ld3<F>(P.cam.horizontal))), vscale<F>(v, ld3<F>(P.cam.vertical))), org), offset);
+    path.tm = rng_range<F>(rng, P.cam.time0, P.cam.time1);
+    path.atten = mk<F>(1, 1, 1);
+    path.depth = 0;
+}
+
+// One bounce given the closest hit (rrt.cu:49-76).  Returns true when the path ended, with its
+// radiance; otherwise `path` is the scattered ray.
+template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInfo<F> &best, Path<F> &path, Rng &rng, V3<F> &radiance)
+{
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    radiance = mk<F>(0, 0, 0);
+    if (best.idx < 0) {
+        // sky, rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50)
+        const V3<F> ud = vunit<F>(path.d);
+        const F t = (F)0.5 * (ud.y + (F)1.0);
+        const V3<F> c = vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0)));
+        radiance = vmul<F>(path.atten, c);
+        return true;
+    }
+    // hit record: sphere.h:51-55 / moving_sphere.h:50-55 / triangle.h:64-67
+    const V3<F> hp = vadd<F>(path.o, vscale<F>(best.t, path.d)); // ray.h:17
+    V3<F> outward;
+    int mat_idx;
+    if (best.idx < msph_base) {
+        const SphereHot<F> g = P.sph_hot[best.idx];
+        const SphereCold<F> cold = P.sph_cold[best.idx];
+        outward = vdiv<F>(vsub<F>(hp, mk<F>(g.cx, g.cy, g.cz)), cold.radius);
+        mat_idx = cold.mat;
+    }
+    else if (best.idx < tri_base) {
+        const MovingSphereRec<F> m = P.msph[best.idx - msph_base];
+        outward = vdiv<F>(vsub<F>(hp, msphere_center<F>(m, path.tm)), m.radius);
+        mat_idx = m.mat;
+    }
+    else {
+        const TriangleRec<F> &tr = P.tri[best.idx - tri_base];
+        outward = ld3<F>(tr.n);
+        mat_idx = tr.mat;
+    }
+    const bool front_face = vdot<F>(path.d, outward) < 0; // hittable.h:18
+    const V3<F> n = front_face ? outward : vneg<F>(outward);
+    const MaterialRec<F> m = P.mat[mat_idx];
+    V3<F> new_d;
+    bool scattered = true;
+    V3<F> albedo = mk<F>(m.r, m.g, m.b);
+    if (m.type != 2) {
+        const V3<F> rs = in_unit_sphere<F>(rng); // both lambertian and metal draw it (material.h:24,54)
+        if (m.type == 0) {
+            // lambertian, material.h:21-32
+            new_d = vadd<F>(n, vunit<F>(rs));
+            const double tiny = 1e-8; // vec3.h:65 compares in double
+            if (((double)ffabs(new_d.x) < tiny) && ((double)ffabs(new_d.y) < tiny) && ((double)ffabs(new_d.z) < tiny)) new_d = n;
+        }
+        else {
+            // metal, material.h:50-57
+            const V3<F> ud = vunit<F>(path.d);
+            const V3<F> reflected = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n)); // vec3.h:156
+            new_d = vadd<F>(reflected, vscale<F>(m.param, rs));
+            scattered = vdot<F>(new_d, n) > 0;
+        }
+    }
+    else {
+        // dielectric, material.h:76-96
+        albedo = mk<F>((F)1.0, (F)1.0, (F)1.0);
+        const F ratio = front_face ? ((F)1.0 / m.param) : m.param;
+        const V3<F> ud = vunit<F>(path.d);
+        const F cos_theta = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
+        const F sin_theta = fsqrt((F)1.0 - cos_theta * cos_theta);
+        bool reflect_it = ratio * sin_theta > (F)1.0;
+        if (!reflect_it) { // the uniform is drawn only here (short-circuit ||, material.h:89)
+            F r0 = ((F)1 - ratio) / ((F)1 + ratio);
+            r0 = r0 * r0;
+            const F refl = r0 + ((F)1 - r0) * pow5((F)1 - cos_theta);
+            reflect_it = refl > rng_uniform<F>(rng);
+        }
+        if (reflect_it)
+            new_d = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n));
+        else {
+            // refract, vec3.h:158-164
+            const F ct = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
+            const V3<F> perp = vscale<F>(ratio, vadd<F>(ud, vscale<F>(ct, n)));
+            const V3<F> par = vscale<F>(-fsqrt(ffabs((F)1.0 - vlen2<F>(perp))), n);
+            new_d = vadd<F>(perp, par);
+        }
+    }
+    if (!scattered) return true; // absorbed, rrt.cu:65
+    path.atten = vmul<F>(path.atten, albedo); // rrt.cu:58
+    path.o = hp;
+    path.d = new_d; // time unchanged (material.h:29)
+    path.depth += 1;
+    return path.depth >= P.max_depth; // rrt.cu:47,78: radiance stays 0
+}
+
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
@@ -327,11 +456,12 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
     // wave-uniform task pool
     uint32_t pool_next = 0, pool_end = 0;
     bool queue_dry = false;
+    int dry_iters = 0; // loop iterations since this wave found the queue dry
 
     // lane state
     bool alive = true, need_task = true, need_ray = false;
     uint32_t task = 0;
-    int px_i = 0, px_j = 0, s_cur = 0, s_end = 0;
+    int s_cur = 0, s_end = 0; // (the pixel is re-derived from `task` at each camera ray: two VGPRs = one wave of occupancy)
     V3<F> acc = mk<F>(0, 0, 0);
     Path<F> path;
     path.o = path.d = path.atten = mk<F>(0, 0, 0);
@@ -339,8 +469,20 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
     path.depth = 0;
     Rng rng = {0, 0, 0};
     uint32_t n_segments = 0, n_candidates = 0;
+#ifdef RRTX_DIAG // timing diagnostics (never in the product build): per-wave real-time stamps
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long diag_dry = 0;
+    uint32_t diag_iters = 0, diag_iters_dry = 0;
+#endif
 
     for (;;) {
+#ifdef RRTX_DIAG
+        diag_iters += 1;
+        if (queue_dry) {
+            if (!diag_dry) diag_dry = __builtin_amdgcn_s_memrealtime();
+            diag_iters_dry += 1;
+        }
+#endif
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
         uint64_t want = __ballot(need_task);
         while (want != 0ull) {
@@ -361,15 +503,10 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
             if (need_task && rank < avail) {
                 task = pool_next + rank;
                 need_task = false;
-                // task -> (local pixel, sample chunk)
-                const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
-                const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
-                const uint32_t lr = q / (uint32_t)P.W;
-                px_i = (int)(q - lr * (uint32_t)P.W);
-                const uint32_t tile = lr / (uint32_t)P.tile_rows;
-                px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
-                s_cur = (int)c * P.chunk;
-                s_end = s_cur + P.chunk < P.spp ? s_cur + P.chunk : P.spp;
+                {
+                    int pi, pj;
+                    task_decode<F>(P, task, pi, pj, s_cur, s_end);
+                }
                 acc = mk<F>(0, 0, 0);
                 need_ray = true;
             }
@@ -381,28 +518,46 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
             alive = false;
             need_task = false;
         }
-        if (__ballot(alive) == 0ull) break;
+        {
+            const uint64_t live = __ballot(alive);
+            if (live == 0ull) break;
+            // ---------------- hand-off to the tail kernel --------------------------------------------
+            // Once the queue is dry, a wave runs on with fewer and fewer live lanes (in the end the
+            // 0.36 % of paths that bounce 50 times), and a lone wave needs ~10 us per segment of the
+            // lane-per-ray scan: that tail cost ~6 ms per launch whatever the frame size.  Below
+            // `handoff_lanes` live lanes the wave parks its unfinished work items (pixel, sample, ray,
+            // attenuation, RNG position, partial sum) in HBM and exits; tail_kernel finishes them one
+            // item per WAVE, with the 64 lanes splitting the primitive list.
+            // ... or after `handoff_iters` more iterations, whatever is still alive: a wave with a dozen
+            // long paths would otherwise keep the whole launch waiting for ~70 full-price iterations.
+            if (queue_dry) dry_iters += 1;
+            if (queue_dry && P.handoff_lanes > 0 && ((int)__popcll(live) <= P.handoff_lanes || dry_iters > P.handoff_iters)) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.tail_count, (uint32_t)__popcll(live)); // every lane still executes here; lane 0 speaks for the wave
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (alive) {
+                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+                    TailItem<F> it;
+                    it.task = task, it.s_cur = s_cur, it.depth = path.depth, it.need_ray = need_ray ? 1u : 0u;
+                    it.k0 = rng.k0, it.k1 = rng.k1, it.n = rng.n, it.pad = 0;
+                    it.acc[0] = acc.x, it.acc[1] = acc.y, it.acc[2] = acc.z;
+                    it.o[0] = path.o.x, it.o[1] = path.o.y, it.o[2] = path.o.z;
+                    it.d[0] = path.d.x, it.d[1] = path.d.y, it.d[2] = path.d.z;
+                    it.tm = path.tm;
+                    it.atten[0] = path.atten.x, it.atten[1] = path.atten.y, it.atten[2] = path.atten.z;
+                    P.tail_items[slot] = it;
+                }
+                break;
+            }
+        }
 
         if (alive) {
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
             if (need_ray) {
                 need_ray = false;
-                rng_open(rng, P.seed, (uint32_t)(px_j * P.W + px_i), (uint32_t)s_cur);
-                const F u = ((F)px_i + rng_uniform<F>(rng)) / (F)(P.W - 1);
-                const F v = ((F)px_j + rng_uniform<F>(rng)) / (F)(P.H - 1);
-                F dx, dy;
-                do { // random_in_unit_disk, vec3.h:127-134
-                    dx = rng_range<F>(rng, (F)-1, (F)1);
-                    dy = rng_range<F>(rng, (F)-1, (F)1);
-                } while (dx * dx + dy * dy >= 1); // + 0*0 of the z component changes nothing
-                const F rdx = P.cam.lens_radius * dx, rdy = P.cam.lens_radius * dy;
-                const V3<F> offset = vadd<F>(vscale<F>(rdx, ld3<F>(P.cam.u)), vscale<F>(rdy, ld3<F>(P.cam.v)));
-                const V3<F> org = ld3<F>(P.cam.origin);
-                path.o = vadd<F>(org, offset);
-                path.d = vsub<F>(vsub<F>(vadd<F>(vadd<F>(ld3<F>(P.cam.llc), vscale<F>(u, ld3<F>(P.cam.horizontal))), vscale<F>(v, ld3<F>(P.cam.vertical))), org), offset);
-                path.tm = rng_range<F>(rng, P.cam.time0, P.cam.time1);
-                path.atten = mk<F>(1, 1, 1);
-                path.depth = 0;
+                int pi, pj, sf, se;
+                task_decode<F>(P, task, pi, pj, sf, se);
+                camera_ray<F>(P, pi, pj, s_cur, rng, path);
             }
 
             bool done = false;
@@ -547,91 +702,7 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
             drain();
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
-            if (best.idx < 0) {
-                // sky, rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50)
-                const V3<F> ud = vunit<F>(path.d);
-                const F t = (F)0.5 * (ud.y + (F)1.0);
-                const V3<F> c = vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0)));
-                radiance = vmul<F>(path.atten, c);
-                done = true;
-            }
-            else {
-                // hit record: sphere.h:51-55 / moving_sphere.h:50-55 / triangle.h:64-67
-                const V3<F> hp = vadd<F>(path.o, vscale<F>(best.t, path.d)); // ray.h:17
-                V3<F> outward;
-                int mat_idx;
-                if (best.idx < msph_base) {
-                    const SphereHot<F> g = P.sph_hot[best.idx];
-                    const SphereCold<F> cold = P.sph_cold[best.idx];
-                    outward = vdiv<F>(vsub<F>(hp, mk<F>(g.cx, g.cy, g.cz)), cold.radius);
-                    mat_idx = cold.mat;
-                }
-                else if (best.idx < tri_base) {
-                    const MovingSphereRec<F> m = P.msph[best.idx - msph_base];
-                    outward = vdiv<F>(vsub<F>(hp, msphere_center<F>(m, path.tm)), m.radius);
-                    mat_idx = m.mat;
-                }
-                else {
-                    const TriangleRec<F> &tr = P.tri[best.idx - tri_base];
-                    outward = ld3<F>(tr.n);
-                    mat_idx = tr.mat;
-                }
-                const bool front_face = vdot<F>(path.d, outward) < 0; // hittable.h:18
-                const V3<F> n = front_face ? outward : vneg<F>(outward);
-                const MaterialRec<F> m = P.mat[mat_idx];
-                V3<F> new_d;
-                bool scattered = true;
-                V3<F> albedo = mk<F>(m.r, m.g, m.b);
-                if (m.type != 2) {
-                    const V3<F> rs = in_unit_sphere<F>(rng); // both lambertian and metal draw it (material.h:24,54)
-                    if (m.type == 0) {
-                        // lambertian, material.h:21-32
-                        new_d = vadd<F>(n, vunit<F>(rs));
-                        const double tiny = 1e-8; // vec3.h:65 compares in double
-                        if (((double)ffabs(new_d.x) < tiny) && ((double)ffabs(new_d.y) < tiny) && ((double)ffabs(new_d.z) < tiny)) new_d = n;
-                    }
-                    else {
-                        // metal, material.h:50-57
-                        const V3<F> ud = vunit<F>(path.d);
-                        const V3<F> reflected = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n)); // vec3.h:156
-                        new_d = vadd<F>(reflected, vscale<F>(m.param, rs));
-                        scattered = vdot<F>(new_d, n) > 0;
-                    }
-                }
-                else {
-                    // dielectric, material.h:76-96
-                    albedo = mk<F>((F)1.0, (F)1.0, (F)1.0);
-                    const F ratio = front_face ? ((F)1.0 / m.param) : m.param;
-                    const V3<F> ud = vunit<F>(path.d);
-                    const F cos_theta = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
-                    const F sin_theta = fsqrt((F)1.0 - cos_theta * cos_theta);
-                    bool reflect_it = ratio * sin_theta > (F)1.0;
-                    if (!reflect_it) { // the uniform is drawn only here (short-circuit ||, material.h:89)
-                        F r0 = ((F)1 - ratio) / ((F)1 + ratio);
-                        r0 = r0 * r0;
-                        const F refl = r0 + ((F)1 - r0) * pow5((F)1 - cos_theta);
-                        reflect_it = refl > rng_uniform<F>(rng);
-                    }
-                    if (reflect_it)
-                        new_d = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n));
-                    else {
-                        // refract, vec3.h:158-164
-                        const F ct = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
-                        const V3<F> perp = vscale<F>(ratio, vadd<F>(ud, vscale<F>(ct, n)));
-                        const V3<F> par = vscale<F>(-fsqrt(ffabs((F)1.0 - vlen2<F>(perp))), n);
-                        new_d = vadd<F>(perp, par);
-                    }
-                }
-                if (scattered) {
-                    path.atten = vmul<F>(path.atten, albedo); // rrt.cu:58
-                    path.o = hp;
-                    path.d = new_d; // time unchanged (material.h:29)
-                    path.depth += 1;
-                    if (path.depth >= P.max_depth) done = true; // rrt.cu:47,78: radiance stays 0
-                }
-                else
-                    done = true; // absorbed, rrt.cu:65
-            }
+            done = shade<F>(P, best, path, rng, radiance);
             } // max_depth > 0
 
             if (done) {
@@ -654,6 +725,153 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
         atomicAdd(&P.counters[0], (unsigned long long)n_segments);
         atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
     }
+#ifdef RRTX_DIAG
+    if (lane == 0) {
+        const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+        unsigned long long *d = P.diag + (size_t)wid * 8;
+        d[0] = diag_t0, d[1] = diag_dry, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = diag_iters, d[4] = diag_iters_dry;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail kernel: finishes the work items the render kernel parked (see "hand-off" there).  One item
+// per wave; every lane carries the same path state, so shading and RNG run in lock step with no
+// divergence, and the scan is turned around: lane l tests primitives l, l + 64, ... with the EXACT
+// reference test (no filter needed at 8 primitives per lane), then a butterfly picks the winner
+// with the sequential scan's tie rules — equal t: the LAST sphere-like primitive wins
+// (sphere.h:46-48 accepts root == t_max); a triangle never displaces an equal t (triangle.h:63),
+// so among triangles the FIRST wins and any sphere beats it.  Same arithmetic per primitive as the
+// lane-per-ray scan, hence the same bits; a segment costs ~0.6k instead of ~4.4k wave-instructions.
+// ---------------------------------------------------------------------------------------------
+template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kernel(const KernelParams<F> P)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlockThreads) >> 6;
+    const uint32_t n_items = *P.tail_count;
+#ifdef RRTX_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const F t_min = (F)0.001;
+    const int n_sph = P.n_sph, n_msph = P.n_msph, n_tri = P.n_tri;
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + n_msph;
+    uint32_t n_segments = 0;
+
+    (void)n_waves;
+    for (;;) {
+        // items are pulled from a cursor (they differ 100x in length: static striding leaves most
+        // waves idle while a few chew through the long ones)
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(P.tail_count + 1, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const TailItem<F> it = P.tail_items[item];
+        int px_i, px_j, s_first, s_end;
+        task_decode<F>(P, it.task, px_i, px_j, s_first, s_end);
+        int s_cur = it.s_cur;
+        bool need_ray = it.need_ray != 0;
+        V3<F> acc = mk<F>(it.acc[0], it.acc[1], it.acc[2]);
+        Path<F> path;
+        path.o = mk<F>(it.o[0], it.o[1], it.o[2]);
+        path.d = mk<F>(it.d[0], it.d[1], it.d[2]);
+        path.tm = it.tm;
+        path.atten = mk<F>(it.atten[0], it.atten[1], it.atten[2]);
+        path.depth = it.depth;
+        Rng rng = {it.k0, it.k1, it.n};
+
+        while (s_cur < s_end) {
+            if (need_ray) {
+                need_ray = false;
+                camera_ray<F>(P, px_i, px_j, s_cur, rng, path);
+            }
+            bool done = false;
+            V3<F> radiance = mk<F>(0, 0, 0);
+            if (P.max_depth <= 0)
+                done = true;
+            else {
+                n_segments += 1;
+                const F a = vlen2<F>(path.d);
+                HitInfo<F> lb;
+                lb.t = Limits<F>::inf();
+                lb.idx = -1;
+                // The split scan + butterfly equals the sequential scan whenever no root is NaN; with a
+                // finite scene (checked on the host) that holds for every ray whose magnitudes cannot
+                // overflow the discriminant.  Anything else (non-finite or absurd rays) takes the plain
+                // sequential scan on every lane: the reference's semantics, NaN behaviour included.
+                const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
+                const bool sane = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big();
+                if (sane) {
+                    for (int p = lane; p < n_sph; p += 64) {
+                        const SphereHot<F> g = P.sph_hot[p];
+                        refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
+                    }
+                    for (int q = lane; q < n_msph; q += 64) {
+                        const MovingSphereRec<F> ms = P.msph[q];
+                        const V3<F> cen = msphere_center<F>(ms, path.tm);
+                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, lb);
+                    }
+                    for (int q = lane; q < n_tri; q += 64) {
+                        F tt;
+                        if (triangle_test<F, true>(P.tri[q], path, t_min, lb.t, tt)) {
+                            lb.t = tt;
+                            lb.idx = tri_base + q;
+                        }
+                    }
+                    // rank: sphere-like -> its index (later wins ties); triangle -> negative (earlier wins, loses to spheres)
+                    int rank = lb.idx < tri_base ? lb.idx : -lb.idx - 1;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const F ot = __shfl_xor(lb.t, off);
+                        const int oi = __shfl_xor(lb.idx, off);
+                        const int orank = __shfl_xor(rank, off);
+                        if (ot < lb.t || (ot == lb.t && orank > rank)) {
+                            lb.t = ot;
+                            lb.idx = oi;
+                            rank = orank;
+                        }
+                    }
+                }
+                else {
+                    for (int p = 0; p < n_sph; ++p) {
+                        const SphereHot<F> g = P.sph_hot[p];
+                        refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
+                    }
+                    for (int q = 0; q < n_msph; ++q) {
+                        const MovingSphereRec<F> ms = P.msph[q];
+                        const V3<F> cen = msphere_center<F>(ms, path.tm);
+                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, lb);
+                    }
+                    for (int q = 0; q < n_tri; ++q) {
+                        F tt;
+                        if (triangle_test<F, true>(P.tri[q], path, t_min, lb.t, tt)) {
+                            lb.t = tt;
+                            lb.idx = tri_base + q;
+                        }
+                    }
+                }
+                done = shade<F>(P, lb, path, rng, radiance);
+            }
+            if (done) {
+                acc = vadd<F>(acc, radiance);
+                s_cur += 1;
+                need_ray = true;
+            }
+        }
+        if (lane == 0) {
+            F *o = P.out + (size_t)it.task * 3;
+            o[0] = acc.x;
+            o[1] = acc.y;
+            o[2] = acc.z;
+        }
+    }
+    if (P.collect_stats && lane == 0 && n_segments) atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+#ifdef RRTX_DIAG
+    if (lane == 0) {
+        unsigned long long *d = P.diag + (size_t)(65536 + wave_id) * 8;
+        d[0] = diag_t0, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = n_segments, d[4] = n_items;
+    }
+#endif
 }
 
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
@@ -688,6 +906,11 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
     default: return launch_variant<F, true, 0>(P, grid_blocks, 0, stream);
     }
 }
+template <typename F> hipError_t launch_tail(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tail_kernel<F>, dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    return hipGetLastError();
+}
 template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32_t n_values, int chunks_per_pixel, hipStream_t stream)
 {
     int blocks = (int)((n_values + 255u) / 256u);
@@ -709,6 +932,8 @@ template <typename F> hipError_t render_occupancy(bool filter, int lds_mode, int
 
 template hipError_t launch_render<float>(const KernelParams<float> &, bool, int, int, hipStream_t);
 template hipError_t launch_render<double>(const KernelParams<double> &, bool, int, int, hipStream_t);
+template hipError_t launch_tail<float>(const KernelParams<float> &, int, hipStream_t);
+template hipError_t launch_tail<double>(const KernelParams<double> &, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, uint32_t, int, hipStream_t);
 template hipError_t launch_finalize<double>(const double *, double *, uint32_t, int, hipStream_t);
 template hipError_t render_occupancy<float>(bool, int, int, int *);
