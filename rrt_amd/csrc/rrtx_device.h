@@ -22,7 +22,10 @@ constexpr int kSphereUnroll = 8;  // tests per straight-line block (fp32; fp64 u
 constexpr int kSpherePad = 16;    // the sphere tables are padded to a multiple of this (two blocks)
 constexpr int kLdsSceneBytes = 48 * 1024; // largest scan table mirrored in LDS
 constexpr int kCandCap = 16;      // candidate slots per lane (LDS), flushed when nearly full
-constexpr int kBlockThreads = 256;
+#ifndef RRTX_BLOCK_THREADS
+#define RRTX_BLOCK_THREADS 256
+#endif
+constexpr int kBlockThreads = RRTX_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr uint32_t kTaskBatch = 64; // tasks a wave pulls from the global queue at a time
 // Safety factor of the conservative scan filter, in units of the unit roundoff.  The

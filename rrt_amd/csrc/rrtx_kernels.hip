@@ -176,6 +176,9 @@ template <typename F> RRTX_DEV V3<F> in_unit_sphere(Rng &r)
 #ifndef RRTX_ASM_PUSH
 #define RRTX_ASM_PUSH 1
 #endif
+#ifndef RRTX_LDS_BLOCK
+#define RRTX_LDS_BLOCK 8 // records per LDS-sourced block (4 and 2 were measured: fewer VGPRs, but slower)
+#endif
 
 #ifdef RRTX_EXPERIMENT // timing experiments only (wrong images): 1 = compare only, 2 = compare + branch, no push
 #if RRTX_EXPERIMENT == 1
@@ -628,15 +631,16 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
                 }
             }
             constexpr int kUnroll = SphereUnroll<F>::value;
-            // one block of kUnroll tests; FROM_LDS selects the operand source
-            auto scan_block = [&](int k0, auto from_lds_c) {
+            // one straight-line block of N tests; FROM_LDS selects the operand source
+            auto scan_block = [&](int k0, auto from_lds_c, auto n_c) {
                 constexpr bool FROM_LDS = decltype(from_lds_c)::value != 0;
-                if (__ballot(cnt > (uint32_t)(kCandCap - kUnroll)) != 0ull) drain();
-                // the block's records first (two s_load_dwordx16, or kUnroll ds_read_b128 broadcasts),
-                // then kUnroll x {test, push}
-                F bcx[kUnroll], bcy[kUnroll], bcz[kUnroll], bw[kUnroll];
+                constexpr int N = decltype(n_c)::value;
+                if (__ballot(cnt > (uint32_t)(kCandCap - N)) != 0ull) drain();
+                // the block's records first (s_load_dwordx16s, or N ds_read_b128 broadcasts), then
+                // N x {test, push}
+                F bcx[N], bcy[N], bcz[N], bw[N];
 #pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
+                for (int u = 0; u < N; ++u) {
                     if (FROM_LDS) {
                         const SphereHot<F> r = sph_lds[k0 + u];
                         bcx[u] = r.cx, bcy[u] = r.cy, bcz[u] = r.cz, bw[u] = r.r2;
@@ -662,19 +666,35 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
                     }
                 };
                 test(IntC<0>());
-                test(IntC<1>());
-                test(IntC<2>());
-                test(IntC<3>());
-                if (kUnroll > 4) {
-                    test(IntC<4 % kUnroll>());
-                    test(IntC<5 % kUnroll>());
-                    test(IntC<6 % kUnroll>());
-                    test(IntC<7 % kUnroll>());
+                test(IntC<1 % N>());
+                if (N > 2) {
+                    test(IntC<2 % N>());
+                    test(IntC<3 % N>());
+                }
+                if (N > 4) {
+                    test(IntC<4 % N>());
+                    test(IntC<5 % N>());
+                    test(IntC<6 % N>());
+                    test(IntC<7 % N>());
                 }
             };
-            for (int k0 = 0; k0 < n_sph_pad; k0 += 2 * kUnroll) { // the table is padded to 2 * kUnroll records
-                scan_block(k0, IntC<(LDSMODE == 2)>());
-                scan_block(k0 + kUnroll, IntC<(LDSMODE != 0)>());
+            // LDS blocks are half as long as scalar blocks: half the vector registers for the same bytes
+            constexpr int kLdsN = RRTX_LDS_BLOCK < kUnroll ? RRTX_LDS_BLOCK : kUnroll;
+            for (int k0 = 0; k0 < n_sph_pad; k0 += 2 * kUnroll) { // the tables are padded to 2 * kUnroll records
+                if (LDSMODE == 0) {
+                    scan_block(k0, IntC<0>(), IntC<kUnroll>());
+                    scan_block(k0 + kUnroll, IntC<0>(), IntC<kUnroll>());
+                }
+                else {
+                    if (LDSMODE == 2) {
+#pragma unroll
+                        for (int j = 0; j < kUnroll; j += kLdsN) scan_block(k0 + j, IntC<1>(), IntC<kLdsN>());
+                    }
+                    else
+                        scan_block(k0, IntC<0>(), IntC<kUnroll>());
+#pragma unroll
+                    for (int j = 0; j < kUnroll; j += kLdsN) scan_block(k0 + kUnroll + j, IntC<1>(), IntC<kLdsN>());
+                }
             }
             // phase 1b: moving spheres (center depends on the ray's time: per-lane)
             for (int m = 0; m < n_msph; ++m) {

@@ -265,3 +265,76 @@ def test_cli_matches_the_library(gpu, tmp_path):
     r = subprocess.run([os.path.join(ROOT, "rrtd"), "-i", SCENES["test3"], "-o", str(png), "-w", str(w), "-h", str(h), "-s", str(spp)], capture_output=True)
     assert r.returncode == 0 and b",double," in r.stderr
     assert np.array_equal(np.asarray(Image.open(str(png))), gpu.quantise(fb64, spp))
+
+
+# ---- scan variants: every operand source / filter / tail combination is the same image ------------
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_scan_variants_are_bit_identical(gpu, fp64):
+    # flags: 1 exact scan (reference discriminant in phase 1), 2 filter + scalar loads only, 0 default
+    # (hybrid scalar/LDS for fp32, scalar for fp64), 4 filter + LDS only, 8 no tail kernel
+    w, h, spp = 96, 64, 6
+    o = Oracle(SCENES["final"], w, h, fp64)
+    want, so = o.render(spp, 50, 1984, order=1)
+    sc = gpu.Scene(SCENES["final"], w, h, fp64=fp64)
+    for flags in (1, 2, 0, 4, 8, 1 | 8, 4 | 8):
+        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=-1, flags=flags)
+        fb = r.render(sc)
+        assert np.array_equal(fb, want), "flags=%d" % flags
+        assert r.stats["segments"] == so["segments"]
+        assert r.stats["scan_filter"] == (0 if flags & 1 else 1)
+        r.close()
+
+
+def test_hand_off_thresholds_do_not_change_the_image(gpu):
+    w, h, spp = 200, 120, 24  # enough work for the queue to matter, small enough for the oracle
+    want, _ = Oracle(SCENES["final"], w, h, False).render(spp, 50, 1984, order=1, chunk=8)
+    sc = gpu.Scene(SCENES["final"], w, h)
+    for lanes, iters in ((1, 1), (7, 8), (64, 1), (32, 1000)):
+        r = gpu.Rrt(w, h, spp, 50, handoff_lanes=lanes, handoff_iters=iters)
+        assert np.array_equal(r.render(sc), want), (lanes, iters)
+        r.close()
+
+
+def _write_scene(path, spheres, cam="camera 0 1 6 0 0 0 0 1 0 40 0.05 6"):
+    lines = [cam, "material a lambertian 0.7 0.4 0.3", "material g dielectric 1.5", "material m metal 0.8 0.8 0.9 0.1"]
+    lines += ["sphere %r %r %r %r %s" % s for s in spheres]
+    path.write_text("\n".join(lines) + "\n")
+    return str(path)
+
+
+def test_filter_is_conservative_on_hostile_geometry(gpu, tmp_path):
+    """The 8-op FMA filter may only ADD candidates.  Scenes built to stress its error bound: a world far
+    from the origin (cancellation in the expanded quadratic), radii from 1e-3 to 1e4, spheres touching and
+    nested so that many rays graze.  Image must equal the oracle's bit for bit, filter on."""
+    rng = np.random.default_rng(5)
+    cases = []
+    # 1. everything shifted 3000 units away from the origin
+    off = np.array([3000.0, -2000.0, 2500.0])
+    sph = [(float(off[0]), float(off[1] - 1000.5), float(off[2]), 1000.0, "a")]
+    for k in range(60):
+        p = off + rng.uniform(-3, 3, 3) * [1, 0.3, 1]
+        sph.append((float(p[0]), float(p[1]), float(p[2]), float(rng.choice([0.05, 0.2, 0.5])), "agm"[k % 3]))
+    cam = "camera %r %r %r %r %r %r 0 1 0 40 0.05 6" % tuple(float(v) for v in (off[0], off[1] + 1, off[2] + 6, off[0], off[1], off[2]))
+    cases.append((sph, cam))
+    # 2. huge and tiny radii together, grazing layouts (kissing spheres along the view axis)
+    sph = [(0.0, -10000.5, 0.0, 10000.0, "a"), (0.0, 0.0, 0.0, 0.5, "g"), (0.0, 0.0, 0.0, 0.499, "g"), (1.0, 0.0, 0.0, 0.5, "m"), (-1.0, 0.0, 0.0, 0.5, "a")]
+    sph += [(0.002 * k - 0.5, 0.6 + 0.002 * k, 0.5, 0.001, "m") for k in range(40)]
+    cases.append((sph, "camera 0 1 6 0 0 0 0 1 0 40 0.05 6"))
+    for i, (sph, cam) in enumerate(cases):
+        f = _write_scene(tmp_path / ("hostile%d.txt" % i), sph, cam)
+        for fp64 in (False, True):
+            fb, st = _render(gpu, f, 64, 40, 4, fp64=fp64, sample_chunk=-1)
+            fo, so = Oracle(f, 64, 40, fp64).render(4, 50, 1984, order=1)
+            assert st["scan_filter"] == 1
+            assert np.array_equal(fb, fo), (i, fp64)
+            assert st["segments"] == so["segments"]
+
+
+def test_out_of_range_scenes_fall_back_to_the_exact_scan(gpu, tmp_path):
+    # magnitudes outside the filter's proven range switch it (and the tail kernel's split scan) off
+    f = _write_scene(tmp_path / "huge.txt", [(0.0, -1e18, 0.0, 1e18, "a"), (0.0, 0.5, 0.0, 0.5, "m")])
+    fb, st = _render(gpu, f, 32, 20, 2, sample_chunk=-1)
+    assert st["scan_filter"] == 0
+    assert np.array_equal(fb, Oracle(f, 32, 20, False).render(2, 50, 1984, order=1)[0])
