@@ -175,8 +175,8 @@ def main():
             "config": {"workload": "scenes/final.txt %dx%d spp=%d d=%d fp32, brute-force list scan (488 spheres)" % (WIDTH, HEIGHT, args.spp, DEPTH), "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", RCCL gather to rank 0" if world > 1 else ""),
                        "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic() if world == 1 and args.spp == SPP else None,
-                         "kernel": "rrtx::render_kernel<float>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
-                         "note": "logical primitive-read roofline (SURVEY.md 8d): the 7.8 KB scene is served from the scalar cache, so frac > 1 is legitimate; the binding unit is VALU issue"},
+                         "kernel": "rrtx::render_kernel<float, true, 1>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
+                         "note": "logical primitive-read roofline (SURVEY.md 8d): a 16-byte record read from the scalar cache or LDS serves all 64 rays of a wave, so frac > 1 is legitimate; binding units: VALU issue (81 %) and the scalar-cache / LDS operand paths (DESIGN.md 3)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
