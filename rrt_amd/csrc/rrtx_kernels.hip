@@ -778,6 +778,22 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + n_msph;
     uint32_t n_segments = 0;
 
+    // this lane's share of the sphere table stays in registers for the whole kernel (the lane -> sphere
+    // mapping never changes): spheres lane, lane + 64, ... up to kResident of them; larger tables
+    // continue from memory
+    constexpr int kResident = 8;
+    SphereHot<F> mine[kResident];
+#pragma unroll
+    for (int j = 0; j < kResident; ++j) {
+        const int p = lane + 64 * j;
+        if (p < n_sph)
+            mine[j] = P.sph_hot[p];
+        else {
+            mine[j].cx = mine[j].cy = mine[j].cz = 0;
+            mine[j].r2 = -Limits<F>::inf(); // discriminant -inf: never a hit
+        }
+    }
+
     (void)n_waves;
     for (;;) {
         // items are pulled from a cursor (they differ 100x in length: static striding leaves most
@@ -822,7 +838,9 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
                 const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
                 const bool sane = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big();
                 if (sane) {
-                    for (int p = lane; p < n_sph; p += 64) {
+#pragma unroll
+                    for (int j = 0; j < kResident; ++j) refine_sphere<F>(mine[j].cx, mine[j].cy, mine[j].cz, mine[j].r2, path, a, t_min, lane + 64 * j, lb);
+                    for (int p = lane + 64 * kResident; p < n_sph; p += 64) {
                         const SphereHot<F> g = P.sph_hot[p];
                         refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
                     }

@@ -338,3 +338,19 @@ def test_out_of_range_scenes_fall_back_to_the_exact_scan(gpu, tmp_path):
     fb, st = _render(gpu, f, 32, 20, 2, sample_chunk=-1)
     assert st["scan_filter"] == 0
     assert np.array_equal(fb, Oracle(f, 32, 20, False).render(2, 50, 1984, order=1)[0])
+
+
+def test_scene_larger_than_the_lds_copy(gpu, tmp_path):
+    # 4000 spheres = 62.5 KB of scan records: more than the LDS mirror holds (48 KB), so the scan falls
+    # back to scalar loads only; also more than 8 spheres per lane in the tail kernel's register share
+    rng = np.random.default_rng(9)
+    sph = [(0.0, -1000.0, 0.0, 1000.0, "a")]
+    for k in range(3999):
+        x, z = rng.uniform(-30, 30, 2)
+        sph.append((float(x), float(rng.uniform(0.1, 0.3)), float(z), float(rng.uniform(0.05, 0.3)), "agm"[k % 3]))
+    f = _write_scene(tmp_path / "many.txt", sph, "camera 10 3 10 0 0 0 0 1 0 35 0.05 14")
+    for fp64 in (False, True):
+        fb, st = _render(gpu, f, 48, 30, 3, fp64=fp64, sample_chunk=-1)
+        fo, so = Oracle(f, 48, 30, fp64).render(3, 50, 1984, order=1)
+        assert np.array_equal(fb, fo), fp64
+        assert st["segments"] == so["segments"] and st["prim_tests"] == so["prim_tests"]

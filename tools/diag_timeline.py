@@ -33,3 +33,7 @@ if len(t):
     d2 = (t[:, 2] - t[:, 0]).astype(np.float64) / 100.0
     ok = t[:, 3] > 0
     print("tail us per segment: median %.2f" % np.median(d2[ok] / t[ok, 3]))
+seg = r.stats["segments"]
+ideal_iters = seg / 64.0 / len(m)
+per_it = np.median(dur / m[:, 3])
+print("segments %d -> ideal iterations per wave %.1f x %.2f us = %.1f us; lane efficiency overall %.3f" % (seg, ideal_iters, per_it, ideal_iters * per_it, seg / 64.0 / m[:, 3].sum()))
