@@ -114,14 +114,22 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible - the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU.  RRTX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks (ranks then share devices and the gather is staged through the host): it checks the
+    # plumbing, its numbers mean nothing.
+    backend = os.environ.get("RRTX_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from rrt_amd.dist import ShardedRenderer
 
-    sr = ShardedRenderer(SCENE, WIDTH, HEIGHT, args.spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=torch.device("cuda", local_rank), collect_stats=True)
+    sr = ShardedRenderer(SCENE, WIDTH, HEIGHT, args.spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=torch.device("cuda", device_index), collect_stats=True)
 
     def barrier():
         if world > 1:
@@ -139,13 +147,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = sr.rrt.collect()
 
     # per-rank kernel statistics -> whole-job roofline numbers
-    vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"])], dtype=torch.float64, device="cuda")
+    vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"])], dtype=torch.float64,
+                       device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         allv = [torch.zeros_like(vec) for _ in range(world)]
         dist.all_gather(allv, vec)

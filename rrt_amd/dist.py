@@ -19,6 +19,17 @@ def shard_rows(image_height, rank, world, tile_rows):
     return rows[(rows // max(1, tile_rows)) % max(1, world) == rank]
 
 
+_INDEX_CACHE = {}
+
+
+def _row_index(image_height, rank, world, tile_rows, device):
+    """shard_rows() as a device tensor, built once (an H2D copy per step would serialise the stream)."""
+    key = (image_height, rank, world, tile_rows, str(device))
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = torch.from_numpy(shard_rows(image_height, rank, world, tile_rows)).to(device)
+    return _INDEX_CACHE[key]
+
+
 def gather_frame(local_rows, image_height, tile_rows=4, group=None, dst=0):
     """Collects every rank's compact row block on `dst` and returns the assembled frame there.
 
@@ -39,13 +50,18 @@ def gather_frame(local_rows, image_height, tile_rows=4, group=None, dst=0):
         send = torch.zeros((most, width, 3), dtype=local_rows.dtype, device=local_rows.device)
         send[: counts[rank]] = local_rows
     send = send.contiguous()
+    # gloo (CPU rehearsals and tests) has no device gather: stage through host memory there.  With
+    # nccl (= RCCL on ROCm) the blocks go device to device over xGMI.
+    staged = dist.get_backend(group) == "gloo" and send.is_cuda
+    home = send.device
+    if staged:
+        send = send.cpu()
     if rank == dst:
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=parts, dst=dst, group=group)
-        frame = torch.empty((image_height, width, 3), dtype=local_rows.dtype, device=local_rows.device)
+        frame = torch.empty((image_height, width, 3), dtype=local_rows.dtype, device=home)
         for r in range(world):
-            idx = torch.from_numpy(shard_rows(image_height, r, world, tile_rows)).to(frame.device)
-            frame.index_copy_(0, idx, parts[r][: counts[r]])
+            frame.index_copy_(0, _row_index(image_height, r, world, tile_rows, home), parts[r][: counts[r]].to(home))
         return frame
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None

@@ -39,3 +39,57 @@ def test_back_to_back_launches_are_independent(gpu):
     assert torch.equal(first, sr.local)
     st = sr.rrt.collect()
     assert st["renders"] == 4 and st["kernel_ms_sum"] >= st["kernel_ms"]
+
+
+def _rank_main(rank, world, port, out_dir, w, h, spp, tile_rows):
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle import scene_path as sp
+        from rrt_amd.dist import ShardedRenderer
+
+        torch.cuda.set_device(0)  # the test box has one GPU: the ranks share it, the gather is staged
+        sr = ShardedRenderer(sp("final"), w, h, spp, tile_rows=tile_rows, device="cuda:0")
+        assert sr.world == world and sr.rank == rank
+        frame = sr.render(dst=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            import numpy as np
+
+            np.save(os.path.join(out_dir, "frame.npy"), frame.cpu().numpy())
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_rows", [(2, 4), (3, 5)])
+def test_sharded_render_across_ranks_equals_the_full_frame(gpu, tmp_path, world, tile_rows):
+    """N > 1 with the real kernels: `world` processes (sharing this box's one GPU) render their row
+    tiles and gather to rank 0; the assembled frame must be the single-process frame bit for bit."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    w, h, spp = 72, 50, 12
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), w, h, spp, tile_rows), nprocs=world, join=True)
+    got = np.load(tmp_path / "frame.npy")
+    r = gpu.Rrt(w, h, spp, 50)
+    want = r.render(gpu.Scene(scene_path("final"), w, h))
+    r.close()
+    assert np.array_equal(got, want)
+    assert np.array_equal(want, Oracle(scene_path("final"), w, h, False).render(spp, 50, 1984, order=1, chunk=8)[0])
