@@ -120,7 +120,11 @@ typedef struct rrtx_params {
     int32_t handoff_lanes;             /* tuning: a wave parks its unfinished items for the tail
                                           kernel once the queue is dry and at most this many of
                                           its 64 lanes are alive; 0 = default (7)              */
-    int32_t reserved[1];               /* [0]: tuning, hand-off iteration cap (0 = default 8)   */
+    int32_t handoff_iters;             /* tuning: ... or this many iterations after the queue ran
+                                          dry, whichever comes first; 0 = default (8)           */
+    int32_t list_passes;               /* tuning: camera-ray LIST passes allowed between two SCAN
+                                          passes; 0 = default (3), -1 = none                    */
+    int32_t reserved[2];
 } rrtx_params;
 
 /* Scan every sphere with the reference's own discriminant (18 VALU ops per test) instead of the
@@ -135,6 +139,11 @@ typedef struct rrtx_params {
 /* Let the render kernel finish every path itself instead of handing the last few to the tail
  * kernel (A/B switch; the images are identical). */
 #define RRTX_FLAG_NO_TAIL_KERNEL 8
+/* Send camera rays through the full scan too instead of their pixel's candidate list (A/B switch). */
+#define RRTX_FLAG_NO_PRIMARY_LISTS 16
+/* Test mode: every camera ray intersected through its list is also scanned sequentially on its
+ * lane; rrtx_stats.list_mismatches counts the rays for which the two disagree (must stay 0). */
+#define RRTX_FLAG_VERIFY_LISTS 32
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
@@ -153,7 +162,7 @@ typedef struct rrtx_stats {
     int32_t local_rows;      /* rows rendered by this shard                                  */
     uint64_t candidates;     /* (ray, primitive) pairs that reached the exact refinement      */
     int32_t scan_filter;     /* 1 if the conservative scan filter was used                    */
-    int32_t reserved1;
+    int32_t list_mismatches; /* RRTX_FLAG_VERIFY_LISTS: camera rays whose list hit != scan hit */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

@@ -48,7 +48,9 @@ class Params(C.Structure):  # rrtx_params
         ("collect_stats", C.c_int32),
         ("flags", C.c_int32),
         ("handoff_lanes", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("handoff_iters", C.c_int32),
+        ("list_passes", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -69,11 +71,14 @@ class Stats(C.Structure):  # rrtx_stats
         ("local_rows", C.c_int32),
         ("candidates", C.c_uint64),
         ("scan_filter", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("list_mismatches", C.c_int32),
     ]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
+
+
+FLAG_SCAN_SCALAR_ONLY, FLAG_SCAN_LDS_ONLY, FLAG_NO_TAIL_KERNEL, FLAG_NO_PRIMARY_LISTS, FLAG_VERIFY_LISTS = 2, 4, 8, 16, 32
 
 
 class SceneDesc(C.Structure):  # rrtx_scene_desc

@@ -80,6 +80,7 @@ struct rrtx_ctx {
     uint32_t *d_queue = nullptr;
     unsigned long long *d_counters = nullptr;
     void *d_partial = nullptr; // [total_tasks][3] when chunks_per_pixel > 1
+    uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
     void *d_tail_items = nullptr; // parked work items (render kernel -> tail kernel)
 #ifdef RRTX_DIAG
     unsigned long long *d_diag = nullptr;
@@ -313,9 +314,12 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.counters = c->d_counters;
     P.collect_stats = c->p.collect_stats;
     P.handoff_lanes = c->tail_capacity ? c->handoff_lanes : 0;
-    P.handoff_iters = c->p.reserved[0] > 0 ? c->p.reserved[0] : kHandoffIters;
+    P.handoff_iters = c->p.handoff_iters > 0 ? c->p.handoff_iters : kHandoffIters;
     P.tail_count = c->d_queue + 1;
     P.tail_items = (TailItem<F> *)c->d_tail_items;
+    P.plist = c->d_plist;
+    P.list_passes = c->d_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
+    P.verify_lists = (c->p.flags & RRTX_FLAG_VERIFY_LISTS) ? 1 : 0;
     P.diag = nullptr;
 #ifdef RRTX_DIAG
     P.diag = c->d_diag;
@@ -459,7 +463,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_plist, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -494,6 +498,26 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
+    // camera-ray candidate lists (one pre-pass per scene: they depend on the camera and the spheres)
+    if (c->d_plist) {
+        (void)hipFree(c->d_plist);
+        c->d_plist = nullptr;
+    }
+    if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0) {
+        const size_t bytes = (size_t)c->local_rows * c->p.image_width * kPlistStride * sizeof(uint16_t);
+        uint16_t *pl = nullptr;
+        RRTX_HIP(hipMalloc((void **)&pl, bytes));
+        if (c->p.fp64) {
+            KernelParams<double> P = make_params<double>(c, nullptr);
+            RRTX_HIP(launch_primary_lists<double>(P, pl, c->stream));
+        }
+        else {
+            KernelParams<float> P = make_params<float>(c, nullptr);
+            RRTX_HIP(launch_primary_lists<float>(P, pl, c->stream));
+        }
+        RRTX_HIP(hipStreamSynchronize(c->stream));
+        c->d_plist = pl;
+    }
     // parked-item buffer: every resident wave can park at most kHandoffLanes items
     if (c->d_tail_items) {
         (void)hipFree(c->d_tail_items);
@@ -535,7 +559,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     }
     if (c->total_tasks == 0) return RRTX_OK;
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 12, st)); // task cursor, parked-item count, tail cursor
-    if (c->p.collect_stats) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 16, st));
+    if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 24, st));
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->chunks_per_pixel > 1 ? c->d_partial : d_rows;
@@ -587,8 +611,9 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
         if (c->p.collect_stats) {
-            unsigned long long ctr[2] = {0, 0};
+            unsigned long long ctr[3] = {0, 0, 0};
             RRTX_HIP(hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
+            stats->list_mismatches = (int32_t)(ctr[2] > 0x7fffffffull ? 0x7fffffffull : ctr[2]);
             const unsigned long long seg = ctr[0];
             stats->segments = seg;
             stats->candidates = ctr[1];

@@ -34,6 +34,9 @@ constexpr int kFilterK = 256;
 // A wave of the render kernel hands its unfinished items to the tail kernel once the queue is dry and
 // at most this many of its lanes are alive (break-even of one-ray-per-wave against one-ray-per-lane).
 constexpr int kHandoffLanes = 7;
+constexpr int kPlistCap = 15;    // sphere indices per pixel in the camera-ray candidate lists ...
+constexpr int kPlistStride = 16; // ... stored as uint16 [count | 0xFFFF, idx...]: 32 bytes per pixel
+constexpr int kListPasses = 3;   // LIST passes allowed between two SCAN passes (measured: 1 -> 80.9, 2 -> 79.8, 3 -> 79.0, 6 -> 78.7 ms)
 constexpr int kHandoffIters = 8; // ... and after this many iterations past queue-dry regardless of the lane count
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
@@ -104,6 +107,9 @@ template <typename F> struct KernelParams {
     uint32_t *tail_count;    // [0] number of parked items, [1] the tail kernel's cursor (zeroed before every launch)
     TailItem<F> *tail_items; // capacity: resident waves * handoff_lanes
     unsigned long long *diag; // RRTX_DIAG builds only (timing stamps), otherwise unused
+    const uint16_t *plist;   // camera-ray candidate lists [local pixel][kPlistStride], or nullptr
+    int32_t list_passes;     // 0 = every segment goes through the scan
+    int32_t verify_lists;    // test mode: counters[2] counts camera rays whose list hit differs from the full scan
 };
 
 } // namespace rrtx

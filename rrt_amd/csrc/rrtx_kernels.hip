@@ -177,7 +177,7 @@ template <typename F> RRTX_DEV V3<F> in_unit_sphere(Rng &r)
 #define RRTX_ASM_PUSH 1
 #endif
 #ifndef RRTX_LDS_BLOCK
-#define RRTX_LDS_BLOCK 8 // records per LDS-sourced block (4 and 2 were measured: fewer VGPRs, but slower)
+#define RRTX_LDS_BLOCK 4 // records per LDS-sourced block: 16 VGPRs of operands keep the kernel at 6 waves/SIMD
 #endif
 
 #ifdef RRTX_EXPERIMENT // timing experiments only (wrong images): 1 = compare only, 2 = compare + branch, no push
@@ -432,7 +432,7 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
-template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
 {
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCandCap][64];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records
@@ -472,6 +472,8 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
     path.depth = 0;
     Rng rng = {0, 0, 0};
     uint32_t n_segments = 0, n_candidates = 0;
+    uint32_t plist_count = 0xFFFFu; // header of the current pixel's camera-ray list
+    int list_passes_done = 0;        // wave-uniform: consecutive LIST passes so far
 #ifdef RRTX_DIAG // timing diagnostics (never in the product build): per-wave real-time stamps
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long diag_dry = 0;
@@ -554,15 +556,28 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
             }
         }
 
-        if (alive) {
+        if (alive && need_ray) {
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
-            if (need_ray) {
-                need_ray = false;
-                int pi, pj, sf, se;
-                task_decode<F>(P, task, pi, pj, sf, se);
-                camera_ray<F>(P, pi, pj, s_cur, rng, path);
-            }
+            need_ray = false;
+            int pi, pj, sf, se;
+            task_decode<F>(P, task, pi, pj, sf, se);
+            camera_ray<F>(P, pi, pj, s_cur, rng, path);
+            // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
+            plist_count = P.plist ? (uint32_t)P.plist[(size_t)(task / (uint32_t)P.chunks_per_pixel) * kPlistStride] : 0xFFFFu;
+        }
 
+        // ---------------- pass mode --------------------------------------------------------------------
+        // A camera ray (depth 0) can only hit the few spheres near its pixel's bundle of rays; those are
+        // listed per pixel by primary_lists_kernel.  In a LIST pass the lanes holding a fresh camera ray
+        // intersect it against their own short list (exact test) and shade, while the others wait; after
+        // at most `list_passes` such passes (sky hits regenerate, so a lane may need several) a SCAN pass
+        // runs the 488-sphere scan for every lane, by then almost all on secondary rays.  Every segment
+        // is still intersected exactly once with the exact test in primitive order: same image.
+        const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0;
+        const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
+        list_passes_done = list_pass ? list_passes_done + 1 : 0;
+
+        if (alive && (!list_pass || has_list)) {
             bool done = false;
             V3<F> radiance = mk<F>(0, 0, 0);
             if (P.max_depth <= 0) { // rrt.cu:47 loop body never runs
@@ -575,6 +590,51 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
             HitInfo<F> best;
             best.t = Limits<F>::inf();
             best.idx = -1;
+            if (list_pass) {
+                // exact tests in primitive order: listed spheres, then every moving sphere and triangle
+                const uint16_t *pl = P.plist + (size_t)(task / (uint32_t)P.chunks_per_pixel) * kPlistStride + 1;
+                n_candidates += plist_count;
+                for (uint32_t k = 0; k < plist_count; ++k) {
+                    const int idx = (int)pl[k];
+                    const SphereHot<F> gq = P.sph_hot[idx];
+                    refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, idx, best);
+                }
+                for (int q = 0; q < n_msph; ++q) {
+                    const MovingSphereRec<F> ms = P.msph[q];
+                    const V3<F> cen = msphere_center<F>(ms, path.tm);
+                    refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, best);
+                }
+                for (int q = 0; q < n_tri; ++q) {
+                    F tt;
+                    if (triangle_test<F, true>(P.tri[q], path, t_min, best.t, tt)) {
+                        best.t = tt;
+                        best.idx = tri_base + q;
+                    }
+                }
+                if (VERIFY) { // test build of the kernel: the list must reproduce the full sequential scan
+                    HitInfo<F> full;
+                    full.t = Limits<F>::inf();
+                    full.idx = -1;
+                    for (int q = 0; q < n_sph; ++q) {
+                        const SphereHot<F> gq = P.sph_hot[q];
+                        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
+                    }
+                    for (int q = 0; q < n_msph; ++q) {
+                        const MovingSphereRec<F> ms = P.msph[q];
+                        const V3<F> cen = msphere_center<F>(ms, path.tm);
+                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
+                    }
+                    for (int q = 0; q < n_tri; ++q) {
+                        F tt;
+                        if (triangle_test<F, true>(P.tri[q], path, t_min, full.t, tt)) {
+                            full.t = tt;
+                            full.idx = tri_base + q;
+                        }
+                    }
+                    if (full.idx != best.idx || !(full.t == best.t)) atomicAdd(&P.counters[2], 1ull);
+                }
+            }
+            else {
             uint32_t cnt = 0;
 
             // phase 2 body, used for flushes and at the end
@@ -720,6 +780,7 @@ template <typename F, bool FILTER, int LDSMODE> __global__ void __launch_bounds_
                 }
             }
             drain();
+            } // scan pass
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
             done = shade<F>(P, best, path, rng, radiance);
@@ -912,6 +973,72 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Camera-ray candidate lists.  One thread per pixel of this shard: which static spheres can ANY camera
+// ray of the pixel hit?  camera::get_ray (camera.h:31-38) shoots from a point L of the lens disk
+// (|L - origin| <= lens_radius) through a point T of the focus plane,
+// T = lower_left_corner + s horizontal + t vertical with (s, t) in the pixel's cell
+// [i/(W-1), (i+1)/(W-1)] x [j/(H-1), (j+1)/(H-1)].  Against the central ray (L0 = origin, T0 = cell
+// centre, D = T0 - L0) a point of such a ray at parameter x deviates by at most
+// dev(x) = |1 - x| Rl + |x| rho, with Rl = lens_radius and rho the cell's half extent.  If the ray
+// touches sphere (c, r), then with perp = distance(c, central line), x* = the parameter of the foot
+// point and kappa = (Rl + rho) / |D| < 1:      perp sqrt(1 - kappa^2) <= r + dev(x*).
+// The kernel lists every sphere passing that test with 0.1 % + 1e-5 (|c - L0| + r) of slack (the
+// rays are formed in fp32/fp64, the bound in exact arithmetic); up to kPlistCap per pixel, in index
+// order; more (or kappa >= 0.9, or a degenerate camera) marks the pixel 0xFFFF = always scan.
+// Double arithmetic for both precisions: this runs once per scene.
+// ---------------------------------------------------------------------------------------------
+template <typename F> __global__ void __launch_bounds__(256) primary_lists_kernel(const KernelParams<F> P, uint16_t *plist)
+{
+    const uint32_t n_pixels = (uint32_t)P.local_rows * (uint32_t)P.W;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pixels; q += gridDim.x * blockDim.x) {
+        const uint32_t lr = q / (uint32_t)P.W;
+        const int i = (int)(q - lr * (uint32_t)P.W);
+        const uint32_t tile = lr / (uint32_t)P.tile_rows;
+        const int j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
+        uint16_t *out = plist + (size_t)q * kPlistStride;
+        const double s0 = ((double)i + 0.5) / (double)(P.W - 1), t0 = ((double)j + 0.5) / (double)(P.H - 1);
+        double D[3], len_h = 0, len_v = 0, dd = 0;
+        for (int k = 0; k < 3; ++k) {
+            D[k] = (double)P.cam.llc[k] + s0 * (double)P.cam.horizontal[k] + t0 * (double)P.cam.vertical[k] - (double)P.cam.origin[k];
+            dd += D[k] * D[k];
+            len_h += (double)P.cam.horizontal[k] * (double)P.cam.horizontal[k];
+            len_v += (double)P.cam.vertical[k] * (double)P.cam.vertical[k];
+        }
+        const double dist = sqrt(dd);
+        const double rho = 0.5 * sqrt(len_h) / (double)(P.W - 1) + 0.5 * sqrt(len_v) / (double)(P.H - 1);
+        const double Rl = fabs((double)P.cam.lens_radius);
+        const double kappa = (Rl + rho) / dist;
+        if (!(dist > 0.0) || !(kappa < 0.9) || !(dd < 1e300)) { // also catches NaN
+            out[0] = 0xFFFFu;
+            continue;
+        }
+        const double inv_cos = 1.0 / sqrt(1.0 - kappa * kappa);
+        uint32_t count = 0;
+        bool overflow = false;
+        for (int k = 0; k < P.n_sph; ++k) {
+            const SphereHot<F> g = P.sph_hot[k];
+            const double r = (double)P.sph_cold[k].radius;
+            const double wx = (double)g.cx - (double)P.cam.origin[0], wy = (double)g.cy - (double)P.cam.origin[1], wz = (double)g.cz - (double)P.cam.origin[2];
+            const double w2 = wx * wx + wy * wy + wz * wz;
+            const double wd = wx * D[0] + wy * D[1] + wz * D[2];
+            const double xs = wd / dd;                     // parameter of the foot point
+            double perp2 = w2 - wd * wd / dd;
+            if (perp2 < 0.0) perp2 = 0.0;
+            const double dev = fabs(1.0 - xs) * Rl + fabs(xs) * rho;
+            const double reach = (fabs(r) + dev) * inv_cos * 1.001 + 1e-5 * (sqrt(w2) + fabs(r));
+            if (!(perp2 > reach * reach)) { // (NaN-safe: anything strange is listed)
+                if (count < (uint32_t)kPlistCap)
+                    out[1 + count] = (uint16_t)k;
+                else
+                    overflow = true;
+                count += 1;
+            }
+        }
+        out[0] = overflow ? (uint16_t)0xFFFFu : (uint16_t)count;
+    }
+}
+
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
 // number of devices).  Only launched when chunks_per_pixel > 1.
 template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, uint32_t n_values, int chunks_per_pixel)
@@ -929,20 +1056,30 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
-template <typename F, bool FILTER, int LDSMODE> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
 }
 template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)
 {
     const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
-    if (!filter) return launch_variant<F, false, 0>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
+    if (P.verify_lists) return launch_variant<F, true, 0, true>(P, grid_blocks, 0, stream); // test build: filter + scalar loads + list check
+    if (!filter) return launch_variant<F, false, 0, false>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
     switch (lds_mode) {
-    case 1: return launch_variant<F, true, 1>(P, grid_blocks, lds, stream);
-    case 2: return launch_variant<F, true, 2>(P, grid_blocks, lds, stream);
-    default: return launch_variant<F, true, 0>(P, grid_blocks, 0, stream);
+    case 1: return launch_variant<F, true, 1, false>(P, grid_blocks, lds, stream);
+    case 2: return launch_variant<F, true, 2, false>(P, grid_blocks, lds, stream);
+    default: return launch_variant<F, true, 0, false>(P, grid_blocks, 0, stream);
     }
+}
+template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, uint16_t *plist, hipStream_t stream)
+{
+    const uint32_t n = (uint32_t)P.local_rows * (uint32_t)P.W;
+    int blocks = (int)((n + 255u) / 256u);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(primary_lists_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, plist);
+    return hipGetLastError();
 }
 template <typename F> hipError_t launch_tail(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
 {
@@ -960,16 +1097,18 @@ template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32
 template <typename F> hipError_t render_occupancy(bool filter, int lds_mode, int n_sph_padded, int *blocks_per_cu)
 {
     const size_t lds = lds_mode ? (size_t)n_sph_padded * sizeof(SphereHot<F>) : 0;
-    if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0>, kBlockThreads, 0);
+    if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false>, kBlockThreads, 0);
     switch (lds_mode) {
-    case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1>, kBlockThreads, lds);
-    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2>, kBlockThreads, lds);
-    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0>, kBlockThreads, 0);
+    case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false>, kBlockThreads, lds);
+    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false>, kBlockThreads, lds);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false>, kBlockThreads, 0);
     }
 }
 
 template hipError_t launch_render<float>(const KernelParams<float> &, bool, int, int, hipStream_t);
 template hipError_t launch_render<double>(const KernelParams<double> &, bool, int, int, hipStream_t);
+template hipError_t launch_primary_lists<float>(const KernelParams<float> &, uint16_t *, hipStream_t);
+template hipError_t launch_primary_lists<double>(const KernelParams<double> &, uint16_t *, hipStream_t);
 template hipError_t launch_tail<float>(const KernelParams<float> &, int, hipStream_t);
 template hipError_t launch_tail<double>(const KernelParams<double> &, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, uint32_t, int, hipStream_t);

@@ -354,3 +354,43 @@ def test_scene_larger_than_the_lds_copy(gpu, tmp_path):
         fo, so = Oracle(f, 48, 30, fp64).render(3, 50, 1984, order=1)
         assert np.array_equal(fb, fo), fp64
         assert st["segments"] == so["segments"] and st["prim_tests"] == so["prim_tests"]
+
+
+# ---- camera-ray candidate lists ----------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_camera_ray_lists_reproduce_the_scan(gpu, name, fp64):
+    """RRTX_FLAG_VERIFY_LISTS re-intersects every listed camera ray with the plain sequential scan on
+    its own lane and counts disagreements: the per-pixel lists must be supersets of what the camera
+    rays can hit (defocus blur, shutter time, moving spheres and triangles included)."""
+    w, h, spp = 160, 100, 16
+    sc = gpu.Scene(SCENES[name], w, h, fp64=fp64)
+    r = gpu.Rrt(w, h, spp, 50, fp64=fp64, flags=32)
+    a = r.render(sc)
+    assert r.stats["list_mismatches"] == 0
+    r.close()
+    r = gpu.Rrt(w, h, spp, 50, fp64=fp64, flags=16)  # lists off: every segment through the scan
+    b = r.render(sc)
+    r.close()
+    assert np.array_equal(a, b)
+
+
+def test_camera_ray_lists_with_wide_lenses_and_odd_cameras(gpu, tmp_path):
+    rng = np.random.default_rng(3)
+    sph = [(0.0, -500.0, 0.0, 500.0, "a")] + [(float(rng.uniform(-4, 4)), float(rng.uniform(0.1, 1.5)), float(rng.uniform(-4, 4)), float(rng.uniform(0.05, 0.6)), "agm"[k % 3]) for k in range(80)]
+    cams = ["camera 0 1 6 0 0.5 0 0 1 0 40 2.0 6",        # huge aperture: every pixel sees half the scene
+            "camera 0 1 6 0 0.5 0 0 1 0 40 0.3 2.5",      # focus plane in front of the objects
+            "camera 0.2 0.3 0.1 1 0.4 0.3 0 1 0 100 0.05 1 0 1",  # camera among the spheres, wide fov, shutter
+            "camera 0 30 0.001 0 0 0 0 1 0 20 0.1 30",    # looking straight down
+            "camera 0 1 6 0 0.5 0 0 1 0 40 0.0 6"]        # pinhole
+    for k, cam in enumerate(cams):
+        f = _write_scene(tmp_path / ("cam%d.txt" % k), sph, cam)
+        for w, h in ((64, 40), (33, 57)):
+            sc = gpu.Scene(f, w, h)
+            r = gpu.Rrt(w, h, 8, 50, flags=32, sample_chunk=-1)
+            fb = r.render(sc)
+            assert r.stats["list_mismatches"] == 0, (cam, w, h)
+            r.close()
+            assert np.array_equal(fb, Oracle(f, w, h, False).render(8, 50, 1984, order=1)[0]), (cam, w, h)

@@ -1,4 +1,4 @@
-"""Developer script (GPU box): time one library variant on final.txt 1200x800, default and scalar-only scan."""
+"""Developer script (GPU box): LIST passes per SCAN pass."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,10 +8,10 @@ from _oracle import scene_path
 W, H = 1200, 800
 s = rrt_amd.Scene(scene_path("final"), W, H)
 buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-for flags in (0, 2, 4):
+for lp in (-1, 1, 2, 3, 4, 6, 2):
     out = []
     for spp in (48, 504):
-        r = rrt_amd.Rrt(W, H, spp, 50, flags=flags)
+        r = rrt_amd.Rrt(W, H, spp, 50, list_passes=lp)
         r.set_scene(s)
         for _ in range(2):
             r.render_device(buf.data_ptr(), 0)
@@ -20,6 +20,6 @@ for flags in (0, 2, 4):
             r.render_device(buf.data_ptr(), 0)
         torch.cuda.synchronize()
         st = r.collect()
-        out.append("spp %d: %.2f ms (grid %d)" % (spp, st["kernel_ms_sum"] / st["renders"], st["grid_blocks"]))
+        out.append("spp %d: %.2f ms" % (spp, st["kernel_ms_sum"] / st["renders"]))
         r.close()
-    print(sys.argv[1] if len(sys.argv) > 1 else "", {0: "hybrid", 2: "scalar", 4: "lds   "}[flags], " | ".join(out), "checksum %.6f" % float(buf.double().sum()), flush=True)
+    print("list_passes %2d" % lp, " | ".join(out), "checksum %.6f" % float(buf.double().sum()), flush=True)
