@@ -320,6 +320,15 @@ template <typename F> RRTX_DEV void task_decode(const KernelParams<F> &P, uint32
     s_end = s_first + P.chunk < P.spp ? s_first + P.chunk : P.spp;
 }
 
+// Where a task's partial sum goes: chunk-major [chunk][local pixel][3], so that finalize_kernel reads
+// consecutive pixels with consecutive threads (with one chunk per pixel this IS the local frame).
+template <typename F> RRTX_DEV F *task_slot(const KernelParams<F> &P, uint32_t task)
+{
+    const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
+    const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
+    return P.out + ((size_t)c * ((size_t)P.local_rows * (size_t)P.W) + q) * 3;
+}
+
 // camera ray of sample `s` of pixel (i, j): rrt.cu:112-114, camera.h:31-38
 template <typename F> RRTX_DEV void camera_ray(const KernelParams<F> &P, int px_i, int px_j, int s, Rng &rng, Path<F> &path)
 {
@@ -790,7 +799,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 acc = vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
                 s_cur += 1;
                 if (s_cur == s_end) {
-                    F *o = P.out + (size_t)task * 3;
+                    F *o = task_slot<F>(P, task);
                     o[0] = acc.x;
                     o[1] = acc.y;
                     o[2] = acc.z;
@@ -958,7 +967,7 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
             }
         }
         if (lane == 0) {
-            F *o = P.out + (size_t)it.task * 3;
+            F *o = task_slot<F>(P, it.task);
             o[0] = acc.x;
             o[1] = acc.y;
             o[2] = acc.z;
@@ -1043,12 +1052,11 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
 // number of devices).  Only launched when chunks_per_pixel > 1.
 template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, uint32_t n_values, int chunks_per_pixel)
 {
-    // one thread per (pixel, channel) value: n_values = pixels * 3
+    // one thread per (pixel, channel) value: n_values = pixels * 3; partial is [chunk][pixel][3]
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
-        const uint32_t q = v / 3u, ch = v - q * 3u;
-        const F *p = partial + ((size_t)q * chunks_per_pixel) * 3 + ch;
+        const F *p = partial + v;
         F s = 0;
-        for (int c = 0; c < chunks_per_pixel; ++c) s = s + p[(size_t)c * 3];
+        for (int c = 0; c < chunks_per_pixel; ++c) s = s + p[(size_t)c * n_values];
         fb[v] = s;
     }
 }
