@@ -153,7 +153,8 @@ def main():
     st = sr.rrt.collect()
 
     # per-rank kernel statistics -> whole-job roofline numbers
-    vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"])], dtype=torch.float64,
+    vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"]), float(st["scanned_segments"]),
+                        float(st["candidates"])], dtype=torch.float64,
                        device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         allv = [torch.zeros_like(vec) for _ in range(world)]
@@ -165,6 +166,8 @@ def main():
         kernel_ms = max(float(v[1]) for v in allv)  # slowest rank's mean launch duration
         segments = sum(float(v[2]) for v in allv)
         prim_tests = sum(float(v[3]) for v in allv)
+        scanned = sum(float(v[4]) for v in allv)
+        candidates = sum(float(v[5]) for v in allv)
         samples = WIDTH * HEIGHT * args.spp
         ms_per_step = elapsed / args.steps * 1e3
         achieved = total_bytes / (kernel_ms * 1e-3) / 1e9 / world  # GB/s per GPU
@@ -182,10 +185,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "scenes/final.txt %dx%d spp=%d d=%d fp32, brute-force list scan (488 spheres)" % (WIDTH, HEIGHT, args.spp, DEPTH), "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", RCCL gather to rank 0" if world > 1 else ""),
-                       "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests)},
+                       "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests),
+                       "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic() if world == 1 and args.spp == SPP else None,
                          "kernel": "rrtx::render_kernel<float, true, 1>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
-                         "note": "logical primitive-read roofline (SURVEY.md 8d): a 16-byte record read from the scalar cache or LDS serves all 64 rays of a wave, so frac > 1 is legitimate; binding units: VALU issue (81 %) and the scalar-cache / LDS operand paths (DESIGN.md 3)"},
+                         "note": "logical primitive-read roofline (SURVEY.md 8d): algorithmic bytes = what the reference's list scan reads (segments x 488 spheres x 16 B); a record read from the scalar cache or LDS serves all 64 rays of a wave and camera rays are resolved from per-pixel candidate lists (config.prim_tests_executed_per_launch), so frac > 1 is legitimate; binding unit: VALU issue (DESIGN.md 3)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -163,6 +163,8 @@ typedef struct rrtx_stats {
     uint64_t candidates;     /* (ray, primitive) pairs that reached the exact refinement      */
     int32_t scan_filter;     /* 1 if the conservative scan filter was used                    */
     int32_t list_mismatches; /* RRTX_FLAG_VERIFY_LISTS: camera rays whose list hit != scan hit */
+    uint64_t scanned_segments; /* segments that went through the full primitive scan (the others
+                                  are camera rays resolved from their pixel's candidate list)  */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

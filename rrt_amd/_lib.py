@@ -72,6 +72,7 @@ class Stats(C.Structure):  # rrtx_stats
         ("candidates", C.c_uint64),
         ("scan_filter", C.c_int32),
         ("list_mismatches", C.c_int32),
+        ("scanned_segments", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -559,7 +559,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     }
     if (c->total_tasks == 0) return RRTX_OK;
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 12, st)); // task cursor, parked-item count, tail cursor
-    if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 24, st));
+    if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 32, st));
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->chunks_per_pixel > 1 ? c->d_partial : d_rows;
@@ -611,12 +611,13 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
         if (c->p.collect_stats) {
-            unsigned long long ctr[3] = {0, 0, 0};
+            unsigned long long ctr[4] = {0, 0, 0, 0};
             RRTX_HIP(hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
             stats->list_mismatches = (int32_t)(ctr[2] > 0x7fffffffull ? 0x7fffffffull : ctr[2]);
             const unsigned long long seg = ctr[0];
             stats->segments = seg;
             stats->candidates = ctr[1];
+            stats->scanned_segments = ctr[3];
             const uint64_t nprim = (uint64_t)c->n_sph + c->n_msph + c->n_tri;
             stats->prim_tests = seg * nprim;
             // B_prim = 4 scalars (sphere) / 9 scalars (moving sphere, triangle)

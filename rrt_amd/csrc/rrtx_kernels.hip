@@ -480,7 +480,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
     path.tm = 0;
     path.depth = 0;
     Rng rng = {0, 0, 0};
-    uint32_t n_segments = 0, n_candidates = 0;
+    uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t plist_count = 0xFFFFu; // header of the current pixel's camera-ray list
     int list_passes_done = 0;        // wave-uniform: consecutive LIST passes so far
 #ifdef RRTX_DIAG // timing diagnostics (never in the product build): per-wave real-time stamps
@@ -644,6 +644,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 }
             }
             else {
+            n_scanned += 1;
             uint32_t cnt = 0;
 
             // phase 2 body, used for flushes and at the end
@@ -814,6 +815,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
     if (P.collect_stats) {
         atomicAdd(&P.counters[0], (unsigned long long)n_segments);
         atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
+        atomicAdd(&P.counters[3], (unsigned long long)n_scanned);
     }
 #ifdef RRTX_DIAG
     if (lane == 0) {
@@ -973,7 +975,10 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
             o[2] = acc.z;
         }
     }
-    if (P.collect_stats && lane == 0 && n_segments) atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+    if (P.collect_stats && lane == 0 && n_segments) {
+        atomicAdd(&P.counters[0], (unsigned long long)n_segments);
+        atomicAdd(&P.counters[3], (unsigned long long)n_segments); // the tail kernel tests every primitive
+    }
 #ifdef RRTX_DIAG
     if (lane == 0) {
         unsigned long long *d = P.diag + (size_t)(65536 + wave_id) * 8;
