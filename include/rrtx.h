@@ -124,7 +124,11 @@ typedef struct rrtx_params {
                                           dry, whichever comes first; 0 = default (8)           */
     int32_t list_passes;               /* tuning: camera-ray LIST passes allowed between two SCAN
                                           passes; 0 = default (3), -1 = none                    */
-    int32_t reserved[2];
+    int32_t taper_samples;             /* tuning: this many samples at the end of the work queue are
+                                          handed out one by one instead of in chunks (rounded up to
+                                          whole pixels); 0 = automatic, -1 = none.  Scheduling only:
+                                          the image does not depend on it                        */
+    int32_t reserved[1];
 } rrtx_params;
 
 /* Scan every sphere with the reference's own discriminant (18 VALU ops per test) instead of the

@@ -50,7 +50,8 @@ class Params(C.Structure):  # rrtx_params
         ("handoff_lanes", C.c_int32),
         ("handoff_iters", C.c_int32),
         ("list_passes", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("taper_samples", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

@@ -67,6 +67,8 @@ struct rrtx_ctx {
     int local_rows = 0;
     int chunk = 0, chunks_per_pixel = 0;
     uint32_t total_tasks = 0;
+    uint32_t taper_pixel = 0; // first local pixel cut into single-sample tasks
+    bool use_partial = false; // tasks write partial sums, finalize_kernel forms the frame
     size_t fsize = 4;
     // scene
     bool have_scene = false;
@@ -79,9 +81,11 @@ struct rrtx_ctx {
     // work buffers
     uint32_t *d_queue = nullptr;
     unsigned long long *d_counters = nullptr;
-    void *d_partial = nullptr; // [total_tasks][3] when chunks_per_pixel > 1
+    void *d_partial = nullptr; // [total_tasks][3] unless every pixel is a single task
     uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
     void *d_tail_items = nullptr; // parked work items (render kernel -> tail kernel)
+    void *d_tail_rad = nullptr;   // the results of their work units
+    uint32_t *d_tail_units = nullptr;
 #ifdef RRTX_DIAG
     unsigned long long *d_diag = nullptr;
 #endif
@@ -308,7 +312,10 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.chunk = c->chunk, P.chunks_per_pixel = c->chunks_per_pixel;
     P.local_rows = c->local_rows;
     P.tile_rows = c->p.tile_rows, P.shard_rank = c->p.shard_rank, P.shard_count = c->p.shard_count;
+    P.taper_pixel = c->taper_pixel, P.taper_task_base = c->taper_pixel * (uint32_t)c->chunks_per_pixel;
     P.total_tasks = c->total_tasks;
+    P.div_cpp = make_fastdiv((uint32_t)c->chunks_per_pixel), P.div_spp = make_fastdiv((uint32_t)c->p.samples_per_pixel);
+    P.div_w = make_fastdiv((uint32_t)c->p.image_width), P.div_tile = make_fastdiv((uint32_t)c->p.tile_rows);
     P.queue = c->d_queue;
     P.out = (F *)out;
     P.counters = c->d_counters;
@@ -317,6 +324,8 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.handoff_iters = c->p.handoff_iters > 0 ? c->p.handoff_iters : kHandoffIters;
     P.tail_count = c->d_queue + 1;
     P.tail_items = (TailItem<F> *)c->d_tail_items;
+    P.tail_rad = (F *)c->d_tail_rad;
+    P.tail_units = c->d_tail_units;
     P.plist = c->d_plist;
     P.list_passes = c->d_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
     P.verify_lists = (c->p.flags & RRTX_FLAG_VERIFY_LISTS) ? 1 : 0;
@@ -424,20 +433,28 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     }
     c->chunk = chunk;
     c->chunks_per_pixel = (p.samples_per_pixel + chunk - 1) / chunk;
-    const int64_t tasks = (int64_t)c->local_rows * p.image_width * c->chunks_per_pixel;
+    // the last `taper` samples of the queue go out as single-sample tasks (task_decode in rrtx_kernels.hip)
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, p.device);
+    const int64_t local_pixels = (int64_t)c->local_rows * p.image_width;
+    int64_t taper = p.taper_samples > 0 ? p.taper_samples : (p.taper_samples < 0 || e != hipSuccess ? 0 : kTaperSamplesPerCu * prop.multiProcessorCount);
+    if (chunk <= 1) taper = 0;
+    int64_t tapered_pixels = (taper + p.samples_per_pixel - 1) / p.samples_per_pixel;
+    if (tapered_pixels > local_pixels) tapered_pixels = local_pixels;
+    const int64_t tasks = (local_pixels - tapered_pixels) * c->chunks_per_pixel + tapered_pixels * p.samples_per_pixel;
     if (tasks >= ((int64_t)1 << 31)) {
         delete c;
         return fail(RRTX_E_INVALID, "rrtx_create: too many work items; raise sample_chunk");
     }
     c->total_tasks = (uint32_t)tasks;
+    c->taper_pixel = (uint32_t)(local_pixels - tapered_pixels);
+    c->use_partial = c->chunks_per_pixel > 1 || tapered_pixels > 0;
 
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, p.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 256);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_counters, 256);
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 256);
-    if (e == hipSuccess && c->chunks_per_pixel > 1) e = hipMalloc(&c->d_partial, (size_t)c->total_tasks * 3 * c->fsize + 64);
+    if (e == hipSuccess && c->use_partial) e = hipMalloc(&c->d_partial, (size_t)c->total_tasks * 3 * c->fsize + 64);
 #ifdef RRTX_DIAG
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_diag, (size_t)131072 * 64);
     if (e == hipSuccess) e = hipMemset(c->d_diag, 0, (size_t)131072 * 64);
@@ -463,7 +480,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_plist, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -523,12 +540,22 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         (void)hipFree(c->d_tail_items);
         c->d_tail_items = nullptr;
     }
+    if (c->d_tail_rad) {
+        (void)hipFree(c->d_tail_rad);
+        c->d_tail_rad = nullptr;
+    }
+    if (c->d_tail_units) {
+        (void)hipFree(c->d_tail_units);
+        c->d_tail_units = nullptr;
+    }
     c->tail_capacity = 0;
     if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
         const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
         c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
-        c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 64; // a wave may park all 64 lanes when the iteration cap fires
+        c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
         RRTX_HIP(hipMalloc(&c->d_tail_items, c->tail_capacity * item));
+        RRTX_HIP(hipMalloc(&c->d_tail_rad, c->tail_capacity * kTailSplit * 3 * c->fsize));
+        RRTX_HIP(hipMalloc((void **)&c->d_tail_units, c->tail_capacity * kTailSplit * sizeof(uint32_t)));
         int64_t tb = (int64_t)(c->tail_capacity + kWavesPerBlock - 1) / kWavesPerBlock; // one wave per item at most
         const int64_t cap = (int64_t)c->num_cus * 8;
         c->tail_blocks = (int)(tb < cap ? tb : cap);
@@ -558,24 +585,23 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
         if (rc) return rc;
     }
     if (c->total_tasks == 0) return RRTX_OK;
-    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 12, st)); // task cursor, parked-item count, tail cursor
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 256, st)); // task cursor, parked-item count, tail cursor, unit count; queue-over flag
     if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 32, st));
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
-    void *out = c->chunks_per_pixel > 1 ? c->d_partial : d_rows;
+    void *out = c->use_partial ? c->d_partial : d_rows;
+    const FinalizeShape shape = {(uint32_t)((size_t)c->local_rows * c->p.image_width), c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel};
     if (c->p.fp64) {
         KernelParams<double> P = make_params<double>(c, out);
         RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
         if (c->tail_capacity) RRTX_HIP(launch_tail<double>(P, c->tail_blocks, st));
-        if (c->chunks_per_pixel > 1)
-            RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
+        if (c->use_partial) RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, shape, st));
     }
     else {
         KernelParams<float> P = make_params<float>(c, out);
         RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
         if (c->tail_capacity) RRTX_HIP(launch_tail<float>(P, c->tail_blocks, st));
-        if (c->chunks_per_pixel > 1)
-            RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, (uint32_t)((size_t)c->local_rows * c->p.image_width * 3), c->chunks_per_pixel, st));
+        if (c->use_partial) RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, shape, st));
     }
     RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));
     c->ev_pending = slot + 1;

@@ -27,7 +27,10 @@ constexpr int kCandCap = 16;      // candidate slots per lane (LDS), flushed whe
 #endif
 constexpr int kBlockThreads = RRTX_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
-constexpr uint32_t kTaskBatch = 64; // tasks a wave pulls from the global queue at a time
+constexpr uint32_t kTaskBatch = 64;    // chunk tasks a wave pulls from the global queue at a time, at most ...
+constexpr uint32_t kTaskBatchMin = 8; // ... and at least (guided: batches shrink towards the end of the chunk tasks)
+constexpr uint32_t kQueueOverFlag = 32; // P.queue[32] (its own 128-byte line): set once the cursor has passed the last task
+constexpr uint32_t kTaperBatch = 256; // single-sample tasks per pull, at most (at least kTaskBatch)
 // Safety factor of the conservative scan filter, in units of the unit roundoff.  The
 // analytic bound needs about 160; empirically false negatives appear only below 16.
 constexpr int kFilterK = 256;
@@ -37,6 +40,7 @@ constexpr int kHandoffLanes = 7;
 constexpr int kPlistCap = 15;    // sphere indices per pixel in the camera-ray candidate lists ...
 constexpr int kPlistStride = 16; // ... stored as uint16 [count | 0xFFFF, idx...]: 32 bytes per pixel
 constexpr int kListPasses = 3;   // LIST passes allowed between two SCAN passes (measured: 1 -> 80.9, 2 -> 79.8, 3 -> 79.0, 6 -> 78.7 ms)
+constexpr int kTailSplit = 8;    // a parked item is finished as up to this many independent units (3 bits in tail_units)
 constexpr int kHandoffIters = 8; // ... and after this many iterations past queue-dry regardless of the lane count
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
@@ -82,6 +86,24 @@ template <typename F> struct TailItem {
     F o[3], d[3], tm, atten[3];
 };
 
+// Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,
+// L = ceil(log2 d), shift = L - 1; Granlund & Montgomery).  A runtime udiv costs ~40 VALU instructions
+// and the task decoding needs several per camera ray.
+struct FastDiv {
+    uint32_t m, shift, is_one, d;
+};
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f = {0u, 0u, d <= 1u ? 1u : 0u, d};
+    if (d > 1u) {
+        uint32_t L = 0;
+        while ((1ull << L) < d) ++L;
+        f.m = (uint32_t)(((unsigned __int128)1 << (31 + L)) / d + 1);
+        f.shift = L - 1;
+    }
+    return f;
+}
+
 template <typename F> struct KernelParams {
     const SphereHot<F> *sph_hot;    // n_sph_padded records {cx, cy, cz, r*r}: the exact test
     const SphereHot<F> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter
@@ -97,20 +119,36 @@ template <typename F> struct KernelParams {
     int32_t chunks_per_pixel;
     // shard: local row lr -> global row ((lr / tile_rows) * shard_count + shard_rank) * tile_rows + lr % tile_rows
     int32_t local_rows, tile_rows, shard_rank, shard_count;
-    uint32_t total_tasks;    // local_rows * W * chunks_per_pixel
-    uint32_t *queue;         // global task cursor (zeroed before every launch)
-    F *out;                  // [total_tasks][3]: per-task partial sums (== the local frame when chunks_per_pixel == 1)
+    FastDiv div_cpp, div_spp, div_w, div_tile; // chunks_per_pixel, spp, W, tile_rows
+    uint32_t taper_pixel;    // local pixels from this one on are cut into single-sample tasks (== pixel count: none)
+    uint32_t taper_task_base; // taper_pixel * chunks_per_pixel: index of the first single-sample task
+    uint32_t total_tasks;    // taper_task_base + (local_rows * W - taper_pixel) * spp
+    uint32_t *queue;         // [0] global task cursor, [kQueueOverFlag] "queue over" flag (zeroed before every launch)
+    F *out;                  // [total_tasks][3]: per-task partial sums, see task_slot (== the local frame when every pixel is one task)
     unsigned long long *counters; // [0] segments, [1] candidates refined in phase 2 (only if collect_stats)
     int32_t collect_stats;
     int32_t handoff_lanes;   // 0 = never hand off (the render kernel finishes everything itself)
     int32_t handoff_iters;   // ... and unconditionally this many iterations after the queue ran dry
-    uint32_t *tail_count;    // [0] number of parked items, [1] the tail kernel's cursor (zeroed before every launch)
-    TailItem<F> *tail_items; // capacity: resident waves * handoff_lanes
+    uint32_t *tail_count;    // [0] parked items, [1] the tail kernel's unit cursor, [2] units (zeroed before every launch)
+    TailItem<F> *tail_items; // capacity: resident waves * 64
+    uint32_t *tail_units;    // work units of the parked items: item << 3 | unit
+    F *tail_rad;             // [item][kTailSplit][3] results of the units
     unsigned long long *diag; // RRTX_DIAG builds only (timing stamps), otherwise unused
     const uint16_t *plist;   // camera-ray candidate lists [local pixel][kPlistStride], or nullptr
     int32_t list_passes;     // 0 = every segment goes through the scan
     int32_t verify_lists;    // test mode: counters[2] counts camera rays whose list hit differs from the full scan
 };
+
+// shape of the partial-sum buffer, for finalize_kernel
+struct FinalizeShape {
+    uint32_t n_pixels, taper_pixel; // local pixels; first single-sample pixel
+    int32_t chunks_per_pixel, chunk, spp;
+};
+
+// Samples handed out as single-sample tasks at the end of the queue, per compute unit (automatic
+// setting): about 2 ms of the chip's work on the headline scene, enough for every chunk task to have
+// finished before the queue runs dry.
+constexpr int64_t kTaperSamplesPerCu = 2048 * 24;
 
 } // namespace rrtx
 

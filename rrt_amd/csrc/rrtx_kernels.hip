@@ -37,6 +37,7 @@ template <typename F> struct V3 {
 };
 template <typename F> RRTX_DEV V3<F> mk(F x, F y, F z) { return V3<F>{x, y, z}; }
 template <typename F> RRTX_DEV V3<F> ld3(const F *p) { return V3<F>{p[0], p[1], p[2]}; }
+template <typename F> RRTX_DEV V3<F> ld3(const RRTX_CONST_AS F *p) { return V3<F>{p[0], p[1], p[2]}; }
 template <typename F> RRTX_DEV V3<F> vadd(V3<F> a, V3<F> b) { return mk<F>(a.x + b.x, a.y + b.y, a.z + b.z); }
 template <typename F> RRTX_DEV V3<F> vsub(V3<F> a, V3<F> b) { return mk<F>(a.x - b.x, a.y - b.y, a.z - b.z); }
 template <typename F> RRTX_DEV V3<F> vmul(V3<F> a, V3<F> b) { return mk<F>(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -307,30 +308,76 @@ template <typename F, bool FULL> RRTX_DEV bool triangle_test(const TriangleRec<F
 // ---------------------------------------------------------------------------------------------
 // Pieces shared by the render kernel (one ray per lane) and the tail kernel (one ray per wave)
 // ---------------------------------------------------------------------------------------------
-// task -> (pixel, first/last sample of its chunk)
-template <typename F> RRTX_DEV void task_decode(const KernelParams<F> &P, uint32_t task, int &px_i, int &px_j, int &s_first, int &s_end)
+// Work items.  Local pixels q < taper_pixel are cut into chunks_per_pixel tasks of `chunk` samples
+// (task = q * chunks_per_pixel + c).  The LAST pixels of the queue (q >= taper_pixel) are cut into
+// single-sample tasks (task = taper_task_base + (q - taper_pixel) * spp + s): when the queue runs dry a
+// lane then holds at most one unfinished path instead of half a chunk of them, which is what the
+// end of a launch used to wait for.  finalize_kernel adds those samples chunk by chunk in sample
+// order, so the image does not depend on where the taper starts.
+// The launch parameters as they lie in the kernel-argument segment, behind a pointer the optimiser
+// cannot see through: fields read via cold_params() are s_load-ed where they are used (camera, task
+// decoding: once per sample) instead of being hoisted out of the render loop into SGPRs that the scan
+// needs — the kernel is SGPR-bound, and every spilled SGPR is a v_readlane in somebody's way.
+template <typename F> RRTX_DEV const RRTX_CONST_AS KernelParams<F> *cold_params()
 {
-    const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
-    const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
-    const uint32_t lr = q / (uint32_t)P.W;
-    px_i = (int)(q - lr * (uint32_t)P.W);
-    const uint32_t tile = lr / (uint32_t)P.tile_rows;
-    px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
-    s_first = (int)c * P.chunk;
-    s_end = s_first + P.chunk < P.spp ? s_first + P.chunk : P.spp;
+    const RRTX_CONST_AS KernelParams<F> *p = (const RRTX_CONST_AS KernelParams<F> *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
 }
 
-// Where a task's partial sum goes: chunk-major [chunk][local pixel][3], so that finalize_kernel reads
-// consecutive pixels with consecutive threads (with one chunk per pixel this IS the local frame).
-template <typename F> RRTX_DEV F *task_slot(const KernelParams<F> &P, uint32_t task)
+template <typename FD> RRTX_DEV uint32_t fdiv(uint32_t n, const FD &f) // n / f.d for n < 2^31
 {
-    const uint32_t q = task / (uint32_t)P.chunks_per_pixel;
-    const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
-    return P.out + ((size_t)c * ((size_t)P.local_rows * (size_t)P.W) + q) * 3;
+    const uint32_t q = __umulhi(n, f.m) >> f.shift;
+    return f.is_one ? n : q;
+}
+
+template <typename F, typename PP> RRTX_DEV uint32_t task_pixel(const PP &P, uint32_t task)
+{
+    return task < P.taper_task_base ? fdiv(task, P.div_cpp) : P.taper_pixel + fdiv(task - P.taper_task_base, P.div_spp);
+}
+
+// task -> (pixel, first/last sample)
+template <typename F, typename PP> RRTX_DEV void task_decode(const PP &P, uint32_t task, int &px_i, int &px_j, int &s_first, int &s_end)
+{
+    uint32_t q;
+    if (task < P.taper_task_base) {
+        q = fdiv(task, P.div_cpp);
+        const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
+        s_first = (int)c * P.chunk;
+        s_end = s_first + P.chunk < P.spp ? s_first + P.chunk : P.spp;
+    }
+    else {
+        const uint32_t t = task - P.taper_task_base;
+        const uint32_t dq = fdiv(t, P.div_spp);
+        q = P.taper_pixel + dq;
+        s_first = (int)(t - dq * (uint32_t)P.spp);
+        s_end = s_first + 1;
+    }
+    const uint32_t lr = fdiv(q, P.div_w);
+    px_i = (int)(q - lr * (uint32_t)P.W);
+    const uint32_t tile = fdiv(lr, P.div_tile);
+    px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
+}
+
+// Where a task's partial sum goes.  Chunked pixels: chunk-major [chunk][pixel < taper_pixel][3], so that
+// finalize_kernel reads consecutive pixels with consecutive threads (with one chunk per pixel and no
+// taper this IS the local frame).  Single-sample tasks follow, sample-major [sample][pixel - taper_pixel][3].
+template <typename F, typename PP> RRTX_DEV F *task_slot(const PP &P, uint32_t task)
+{
+    if (task < P.taper_task_base) {
+        const uint32_t q = fdiv(task, P.div_cpp);
+        const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
+        return P.out + ((size_t)c * (size_t)P.taper_pixel + q) * 3;
+    }
+    const uint32_t t = task - P.taper_task_base;
+    const uint32_t dq = fdiv(t, P.div_spp);
+    const uint32_t sidx = t - dq * (uint32_t)P.spp;
+    const size_t n_tapered = (size_t)P.local_rows * (size_t)P.W - (size_t)P.taper_pixel;
+    return P.out + ((size_t)P.taper_task_base + (size_t)sidx * n_tapered + dq) * 3;
 }
 
 // camera ray of sample `s` of pixel (i, j): rrt.cu:112-114, camera.h:31-38
-template <typename F> RRTX_DEV void camera_ray(const KernelParams<F> &P, int px_i, int px_j, int s, Rng &rng, Path<F> &path)
+template <typename F, typename PP> RRTX_DEV void camera_ray(const PP &P, int px_i, int px_j, int s, Rng &rng, Path<F> &path)
 {
     rng_open(rng, P.seed, (uint32_t)(px_j * P.W + px_i), (uint32_t)s);
     const F u = ((F)px_i + rng_uniform<F>(rng)) / (F)(P.W - 1);
@@ -467,8 +514,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
 
     // wave-uniform task pool
     uint32_t pool_next = 0, pool_end = 0;
-    bool queue_dry = false;
-    int dry_iters = 0; // loop iterations since this wave found the queue dry
+    bool queue_dry = false;  // this wave's own pull came back empty
+    bool queue_over = false; // the global cursor has been seen past the end
+    uint32_t cursor_seen = 0, loop_count = 0;
+    const uint32_t n_waves = gridDim.x * (uint32_t)kWavesPerBlock;
+    int dry_iters = 0; // loop iterations since this wave saw the queue over
 
     // lane state
     bool alive = true, need_task = true, need_ray = false;
@@ -486,31 +536,71 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
 #ifdef RRTX_DIAG // timing diagnostics (never in the product build): per-wave real-time stamps
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long diag_dry = 0;
-    uint32_t diag_iters = 0, diag_iters_dry = 0;
+    uint32_t diag_iters = 0, diag_iters_dry = 0, diag_pulls = 0, diag_pull_iter = 0, diag_pull_base = 0;
+    unsigned long long diag_pull_t = 0;
 #endif
 
     for (;;) {
 #ifdef RRTX_DIAG
         diag_iters += 1;
-        if (queue_dry) {
+        if (queue_over) {
             if (!diag_dry) diag_dry = __builtin_amdgcn_s_memrealtime();
             diag_iters_dry += 1;
         }
 #endif
+        // ---------------- the global cursor: is the queue over, and how large a batch to pull ------
+        // The first wave whose pull comes back empty raises a flag; every wave polls it, also those
+        // that need no task: a wave that is slow (the youngest waves
+        // of a SIMD get the fewest issue slots) or holds long tasks would otherwise work through its
+        // pool long after everyone else has left.
+#ifndef RRTX_POLL_MASK
+#define RRTX_POLL_MASK 3u
+#endif
+#ifndef RRTX_EXP_NOPOLL
+        if (!queue_over && (loop_count & RRTX_POLL_MASK) == 0u) {
+            // (a flag on a line of its own: reading the cursor itself, which every pull hits with an
+            // atomic, costs ~30 us a poll)
+            uint32_t over = 0;
+            if (lane == 0) over = __hip_atomic_load(P.queue + kQueueOverFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            queue_over = __builtin_amdgcn_readfirstlane(over) != 0u;
+        }
+#endif
+        loop_count += 1;
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
         uint64_t want = __ballot(need_task);
         while (want != 0ull) {
             if (pool_next == pool_end) {
                 if (queue_dry) break;
+                // guided batches: half of an even share of what is left of the region (chunk tasks, then
+                // single-sample tasks), so that the pools waves are left with shrink towards its end
+                uint32_t batch;
+#ifdef RRTX_EXP_NOGUIDED
+                batch = cursor_seen < P.taper_task_base ? kTaskBatch : kTaperBatch;
+                if (false) {}
+#else
+                if (cursor_seen < P.taper_task_base) {
+                    batch = (P.taper_task_base - cursor_seen) / (2u * n_waves);
+                    batch = batch < kTaskBatchMin ? kTaskBatchMin : (batch > kTaskBatch ? kTaskBatch : batch);
+                }
+                else {
+                    batch = (P.total_tasks > cursor_seen ? P.total_tasks - cursor_seen : 0u) / (2u * n_waves);
+                    batch = batch < kTaskBatch ? kTaskBatch : (batch > kTaperBatch ? kTaperBatch : batch);
+                }
+#endif
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.queue, kTaskBatch);
+                if (lane == 0) base = atomicAdd(P.queue, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
+                cursor_seen = base + batch;
                 if (base >= P.total_tasks) {
-                    queue_dry = true;
+                    if (lane == 0 && !queue_over) __hip_atomic_store(P.queue + kQueueOverFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    queue_dry = queue_over = true;
                     break;
                 }
                 pool_next = base;
-                pool_end = (P.total_tasks - base < kTaskBatch) ? P.total_tasks : base + kTaskBatch;
+                pool_end = (P.total_tasks - base < batch) ? P.total_tasks : base + batch;
+#ifdef RRTX_DIAG
+                diag_pulls += 1, diag_pull_iter = diag_iters, diag_pull_base = base, diag_pull_t = __builtin_amdgcn_s_memrealtime();
+#endif
             }
             const uint32_t avail = pool_end - pool_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u)); // set bits below this lane
@@ -519,7 +609,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 need_task = false;
                 {
                     int pi, pj;
-                    task_decode<F>(P, task, pi, pj, s_cur, s_end);
+                    task_decode<F>(*cold_params<F>(), task, pi, pj, s_cur, s_end);
                 }
                 acc = mk<F>(0, 0, 0);
                 need_ray = true;
@@ -536,30 +626,58 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
             const uint64_t live = __ballot(alive);
             if (live == 0ull) break;
             // ---------------- hand-off to the tail kernel --------------------------------------------
-            // Once the queue is dry, a wave runs on with fewer and fewer live lanes (in the end the
+            // Once the queue is over, a wave runs on with fewer and fewer live lanes (in the end the
             // 0.36 % of paths that bounce 50 times), and a lone wave needs ~10 us per segment of the
             // lane-per-ray scan: that tail cost ~6 ms per launch whatever the frame size.  Below
             // `handoff_lanes` live lanes the wave parks its unfinished work items (pixel, sample, ray,
-            // attenuation, RNG position, partial sum) in HBM and exits; tail_kernel finishes them one
-            // item per WAVE, with the 64 lanes splitting the primitive list.
-            // ... or after `handoff_iters` more iterations, whatever is still alive: a wave with a dozen
-            // long paths would otherwise keep the whole launch waiting for ~70 full-price iterations.
-            if (queue_dry) dry_iters += 1;
-            if (queue_dry && P.handoff_lanes > 0 && ((int)__popcll(live) <= P.handoff_lanes || dry_iters > P.handoff_iters)) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.tail_count, (uint32_t)__popcll(live)); // every lane still executes here; lane 0 speaks for the wave
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (alive) {
-                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-                    TailItem<F> it;
-                    it.task = task, it.s_cur = s_cur, it.depth = path.depth, it.need_ray = need_ray ? 1u : 0u;
-                    it.k0 = rng.k0, it.k1 = rng.k1, it.n = rng.n, it.pad = 0;
-                    it.acc[0] = acc.x, it.acc[1] = acc.y, it.acc[2] = acc.z;
-                    it.o[0] = path.o.x, it.o[1] = path.o.y, it.o[2] = path.o.z;
-                    it.d[0] = path.d.x, it.d[1] = path.d.y, it.d[2] = path.d.z;
-                    it.tm = path.tm;
-                    it.atten[0] = path.atten.x, it.atten[1] = path.atten.y, it.atten[2] = path.atten.z;
-                    P.tail_items[slot] = it;
+            // attenuation, RNG position, partial sum) in HBM and exits; tail_kernel finishes them.
+            // ... or after `handoff_iters` more iterations, whatever is still alive — and whatever tasks
+            // are left in its pool: the launch then ends a bounded time after the queue does.
+            if (queue_over) dry_iters += 1;
+            if (queue_over && P.handoff_lanes > 0 && pool_end - pool_next <= 64u && ((int)__popcll(live) <= P.handoff_lanes || dry_iters > P.handoff_iters)) {
+                // (every lane still executes here; lane 0 speaks for the wave)
+                auto park = [&](bool active, const TailItem<F> &it, int units) {
+                    const uint64_t who = __ballot(active);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.tail_count, (uint32_t)__popcll(who));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(who >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)who, 0u));
+                    if (active) P.tail_items[slot] = it;
+                    // ... and the item's work units (see tail_kernel), first units first: those are the
+                    // paths already in flight
+                    if (!active) units = 0;
+                    uint64_t has[kTailSplit];
+                    uint32_t total = 0;
+#pragma unroll
+                    for (int k = 0; k < kTailSplit; ++k) {
+                        has[k] = __ballot(units > k);
+                        total += (uint32_t)__popcll(has[k]);
+                    }
+                    uint32_t ubase = 0;
+                    if (lane == 0) ubase = atomicAdd(P.tail_count + 2, total);
+                    ubase = __builtin_amdgcn_readfirstlane(ubase);
+#pragma unroll
+                    for (int k = 0; k < kTailSplit; ++k) {
+                        if (units > k) P.tail_units[ubase + __builtin_amdgcn_mbcnt_hi((uint32_t)(has[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has[k], 0u))] = (slot << 3) | (uint32_t)k;
+                        ubase += (uint32_t)__popcll(has[k]);
+                    }
+                };
+                TailItem<F> it;
+                it.task = task, it.s_cur = s_cur, it.depth = path.depth, it.need_ray = need_ray ? 1u : 0u;
+                it.k0 = rng.k0, it.k1 = rng.k1, it.n = rng.n, it.pad = 0;
+                it.acc[0] = acc.x, it.acc[1] = acc.y, it.acc[2] = acc.z;
+                it.o[0] = path.o.x, it.o[1] = path.o.y, it.o[2] = path.o.z;
+                it.d[0] = path.d.x, it.d[1] = path.d.y, it.d[2] = path.d.z;
+                it.tm = path.tm;
+                it.atten[0] = path.atten.x, it.atten[1] = path.atten.y, it.atten[2] = path.atten.z;
+                park(alive, it, s_end - s_cur < kTailSplit ? s_end - s_cur : kTailSplit);
+                if (pool_next != pool_end) { // tasks nobody started
+                    const bool mine = pool_next + (uint32_t)lane < pool_end;
+                    TailItem<F> fresh = {};
+                    int pi, pj, sf = 0, se = 0;
+                    if (mine) task_decode<F>(*cold_params<F>(), pool_next + (uint32_t)lane, pi, pj, sf, se);
+                    fresh.task = pool_next + (uint32_t)lane, fresh.s_cur = sf, fresh.need_ray = 1u;
+                    park(mine, fresh, se - sf < kTailSplit ? se - sf : kTailSplit);
                 }
                 break;
             }
@@ -569,10 +687,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
             need_ray = false;
             int pi, pj, sf, se;
-            task_decode<F>(P, task, pi, pj, sf, se);
-            camera_ray<F>(P, pi, pj, s_cur, rng, path);
+            const auto &C = *cold_params<F>();
+            task_decode<F>(C, task, pi, pj, sf, se);
+            camera_ray<F>(C, pi, pj, s_cur, rng, path);
             // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
-            plist_count = P.plist ? (uint32_t)P.plist[(size_t)(task / (uint32_t)P.chunks_per_pixel) * kPlistStride] : 0xFFFFu;
+            plist_count = C.plist ? (uint32_t)C.plist[(size_t)task_pixel<F>(C, task) * kPlistStride] : 0xFFFFu;
         }
 
         // ---------------- pass mode --------------------------------------------------------------------
@@ -601,7 +720,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
             best.idx = -1;
             if (list_pass) {
                 // exact tests in primitive order: listed spheres, then every moving sphere and triangle
-                const uint16_t *pl = P.plist + (size_t)(task / (uint32_t)P.chunks_per_pixel) * kPlistStride + 1;
+                const auto &C = *cold_params<F>();
+                const uint16_t *pl = C.plist + (size_t)task_pixel<F>(C, task) * kPlistStride + 1;
                 n_candidates += plist_count;
                 for (uint32_t k = 0; k < plist_count; ++k) {
                     const int idx = (int)pl[k];
@@ -800,7 +920,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 acc = vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
                 s_cur += 1;
                 if (s_cur == s_end) {
-                    F *o = task_slot<F>(P, task);
+                    F *o = task_slot<F>(*cold_params<F>(), task);
                     o[0] = acc.x;
                     o[1] = acc.y;
                     o[2] = acc.z;
@@ -822,75 +942,137 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
         const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
         unsigned long long *d = P.diag + (size_t)wid * 8;
         d[0] = diag_t0, d[1] = diag_dry, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = diag_iters, d[4] = diag_iters_dry;
+        d[5] = diag_pull_t, d[6] = ((unsigned long long)diag_pulls << 32) | diag_pull_iter, d[7] = diag_pull_base;
     }
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tail kernel: finishes the work items the render kernel parked (see "hand-off" there).  One item
-// per wave; every lane carries the same path state, so shading and RNG run in lock step with no
-// divergence, and the scan is turned around: lane l tests primitives l, l + 64, ... with the EXACT
-// reference test (no filter needed at 8 primitives per lane), then a butterfly picks the winner
-// with the sequential scan's tie rules — equal t: the LAST sphere-like primitive wins
-// (sphere.h:46-48 accepts root == t_max); a triangle never displaces an equal t (triangle.h:63),
-// so among triangles the FIRST wins and any sphere beats it.  Same arithmetic per primitive as the
-// lane-per-ray scan, hence the same bits; a segment costs ~0.6k instead of ~4.4k wave-instructions.
+// Tail kernel: finishes the work items the render kernel parked (see "hand-off" there).
+//
+// The parked population is what a launch ends with: a few hundred thousand paths, most of them long
+// (paths are in flight for as long as they are long), each a chain of dependent segments.  G lanes
+// share one ray here (64 / G rays per wave): every lane of a group carries the same path state, so
+// shading and RNG run in lock step, and the scan is turned around: lane `sub` tests primitives sub,
+// sub + G, ... with the EXACT reference test, then a butterfly inside the group picks the winner with
+// the sequential scan's tie rules — equal t: the LAST sphere-like primitive wins (sphere.h:46-48
+// accepts root == t_max); a triangle never displaces an equal t (triangle.h:63), so among triangles
+// the FIRST wins and any sphere beats it.  Same arithmetic per primitive as the lane-per-ray scan,
+// hence the same bits.
+//
+// Work units (written by the render kernel next to the items, P.tail_units): unit 0 of an item
+// continues its partial sum over all but the last kTailSplit - 1 remaining samples of the task, units
+// k >= 1 are those last samples one by one; tail_sum_kernel adds the results in sample order.  That
+// bounds most units to one path.  Units are pulled by the wave in guided batches (large while many
+// remain, one per group at the end) and dealt to the groups as they finish, as the render kernel deals
+// tasks to lanes.
 // ---------------------------------------------------------------------------------------------
-template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kernel(const KernelParams<F> P)
+template <typename F, int G, bool LDS> __global__ void __launch_bounds__(kBlockThreads) tail_kernel(const KernelParams<F> P)
 {
+    // the sphere table is read from a copy in LDS when it fits (the scan is a chain of dependent loads
+    // otherwise: ~1 us each from L2 under load)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    const SphereHot<F> *sph_tab = P.sph_hot;
+    if (LDS) {
+        SphereHot<F> *const copy = (SphereHot<F> *)dyn_lds;
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) copy[i] = P.sph_hot[i];
+        __syncthreads();
+        sph_tab = copy;
+    }
+    constexpr uint32_t kGroups = 64 / G;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_id = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * kBlockThreads) >> 6;
-    const uint32_t n_items = *P.tail_count;
+    const int sub = lane & (G - 1);
+    const uint64_t lanes_below_group = (1ull << (lane & ~(G - 1))) - 1ull;
+    const uint32_t n_waves = gridDim.x * (uint32_t)kWavesPerBlock;
+    const uint32_t n_units = P.tail_count[2];
 #ifdef RRTX_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const F t_min = (F)0.001;
-    const int n_sph = P.n_sph, n_msph = P.n_msph, n_tri = P.n_tri;
-    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + n_msph;
+    const int n_msph = P.n_msph, n_tri = P.n_tri;
+    const int n_sph_pad = P.n_sph_padded, msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + n_msph;
     uint32_t n_segments = 0;
 
-    // this lane's share of the sphere table stays in registers for the whole kernel (the lane -> sphere
-    // mapping never changes): spheres lane, lane + 64, ... up to kResident of them; larger tables
-    // continue from memory
-    constexpr int kResident = 8;
-    SphereHot<F> mine[kResident];
-#pragma unroll
-    for (int j = 0; j < kResident; ++j) {
-        const int p = lane + 64 * j;
-        if (p < n_sph)
-            mine[j] = P.sph_hot[p];
-        else {
-            mine[j].cx = mine[j].cy = mine[j].cz = 0;
-            mine[j].r2 = -Limits<F>::inf(); // discriminant -inf: never a hit
-        }
-    }
+    // wave-uniform pool of units
+    uint32_t pool_next = 0, pool_end = 0, last_base = 0;
+    bool dry = false;
+    // group state (identical in the G lanes of a group)
+    bool have = false, retired = false, need_ray = false, single = false;
+    uint32_t task = 0, out_index = 0;
+    int s_cur = 0, s_end = 0;
+    V3<F> acc = mk<F>(0, 0, 0);
+    Path<F> path;
+    path.o = path.d = path.atten = mk<F>(0, 0, 0);
+    path.tm = 0;
+    path.depth = 0;
+    Rng rng = {0, 0, 0};
 
-    (void)n_waves;
     for (;;) {
-        // items are pulled from a cursor (they differ 100x in length: static striding leaves most
-        // waves idle while a few chew through the long ones)
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(P.tail_count + 1, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const TailItem<F> it = P.tail_items[item];
-        int px_i, px_j, s_first, s_end;
-        task_decode<F>(P, it.task, px_i, px_j, s_first, s_end);
-        int s_cur = it.s_cur;
-        bool need_ray = it.need_ray != 0;
-        V3<F> acc = mk<F>(it.acc[0], it.acc[1], it.acc[2]);
-        Path<F> path;
-        path.o = mk<F>(it.o[0], it.o[1], it.o[2]);
-        path.d = mk<F>(it.d[0], it.d[1], it.d[2]);
-        path.tm = it.tm;
-        path.atten = mk<F>(it.atten[0], it.atten[1], it.atten[2]);
-        path.depth = it.depth;
-        Rng rng = {it.k0, it.k1, it.n};
+        // ---------------- unit hand-out --------------------------------------------------------------
+        bool need = !have && !retired;
+        uint64_t want = __ballot(need);
+        while (want != 0ull) {
+            if (pool_next == pool_end) {
+                if (dry) break;
+                // guided: half of an even share of what is left, between one and eight units per group
+                const uint32_t left = n_units > last_base ? n_units - last_base : 0u;
+                uint32_t batch = left / (2u * n_waves);
+                batch = batch < kGroups ? kGroups : (batch > 8u * kGroups ? 8u * kGroups : batch);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.tail_count + 1, batch);
+                base = __builtin_amdgcn_readfirstlane(base);
+                last_base = base;
+                if (base >= n_units) {
+                    dry = true;
+                    break;
+                }
+                pool_next = base;
+                pool_end = n_units - base < batch ? n_units : base + batch;
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t rank = (uint32_t)__popcll(want & lanes_below_group) / (uint32_t)G; // needy groups before mine
+            if (need && rank < avail) {
+                const uint32_t u = P.tail_units[pool_next + rank];
+                const uint32_t item = u >> 3, k = u & 7u;
+                const TailItem<F> it = P.tail_items[item];
+                task = it.task;
+                int px_i, px_j, s_first, s_task_end;
+                task_decode<F>(P, task, px_i, px_j, s_first, s_task_end);
+                // unit 0: the item's samples but the last kTailSplit - 1; unit k: the k-th of those
+                const int remaining = s_task_end - it.s_cur;
+                const int n0 = remaining > kTailSplit - 1 ? remaining - (kTailSplit - 1) : 1;
+                if (k == 0) {
+                    s_cur = it.s_cur, s_end = it.s_cur + n0;
+                    need_ray = it.need_ray != 0;
+                    acc = mk<F>(it.acc[0], it.acc[1], it.acc[2]);
+                    path.o = mk<F>(it.o[0], it.o[1], it.o[2]);
+                    path.d = mk<F>(it.d[0], it.d[1], it.d[2]);
+                    path.tm = it.tm;
+                    path.atten = mk<F>(it.atten[0], it.atten[1], it.atten[2]);
+                    path.depth = it.depth;
+                    rng.k0 = it.k0, rng.k1 = it.k1, rng.n = it.n;
+                }
+                else {
+                    s_cur = it.s_cur + n0 + (int)k - 1, s_end = s_cur + 1;
+                    need_ray = true;
+                }
+                single = k != 0;
+                out_index = item * (uint32_t)kTailSplit + k;
+                have = true;
+                need = false;
+            }
+            const uint32_t needy = (uint32_t)__popcll(want) / (uint32_t)G;
+            pool_next += needy < avail ? needy : avail;
+            want = __ballot(need);
+        }
+        if (need) retired = true;
+        if (__ballot(have) == 0ull) break;
 
-        while (s_cur < s_end) {
+        if (have) {
             if (need_ray) {
                 need_ray = false;
+                int px_i, px_j, sf, se;
+                task_decode<F>(P, task, px_i, px_j, sf, se);
                 camera_ray<F>(P, px_i, px_j, s_cur, rng, path);
             }
             bool done = false;
@@ -910,18 +1092,22 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
                 const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
                 const bool sane = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big();
                 if (sane) {
+                    // (padding records have r*r = -inf: discriminant -inf, never a hit)
+                    constexpr int U = 4; // loads in flight per lane
+                    for (int p0 = sub; p0 < n_sph_pad; p0 += U * G) {
+                        SphereHot<F> g[U];
 #pragma unroll
-                    for (int j = 0; j < kResident; ++j) refine_sphere<F>(mine[j].cx, mine[j].cy, mine[j].cz, mine[j].r2, path, a, t_min, lane + 64 * j, lb);
-                    for (int p = lane + 64 * kResident; p < n_sph; p += 64) {
-                        const SphereHot<F> g = P.sph_hot[p];
-                        refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
+                        for (int u = 0; u < U; ++u) g[u] = sph_tab[p0 + u * G < n_sph_pad ? p0 + u * G : 0];
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (p0 + u * G < n_sph_pad) refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, g[u].r2, path, a, t_min, p0 + u * G, lb);
                     }
-                    for (int q = lane; q < n_msph; q += 64) {
+                    for (int q = sub; q < n_msph; q += G) {
                         const MovingSphereRec<F> ms = P.msph[q];
                         const V3<F> cen = msphere_center<F>(ms, path.tm);
                         refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, lb);
                     }
-                    for (int q = lane; q < n_tri; q += 64) {
+                    for (int q = sub; q < n_tri; q += G) {
                         F tt;
                         if (triangle_test<F, true>(P.tri[q], path, t_min, lb.t, tt)) {
                             lb.t = tt;
@@ -931,7 +1117,7 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
                     // rank: sphere-like -> its index (later wins ties); triangle -> negative (earlier wins, loses to spheres)
                     int rank = lb.idx < tri_base ? lb.idx : -lb.idx - 1;
 #pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
+                    for (int off = G / 2; off >= 1; off >>= 1) { // stays inside the group
                         const F ot = __shfl_xor(lb.t, off);
                         const int oi = __shfl_xor(lb.idx, off);
                         const int orank = __shfl_xor(rank, off);
@@ -943,7 +1129,7 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
                     }
                 }
                 else {
-                    for (int p = 0; p < n_sph; ++p) {
+                    for (int p = 0; p < P.n_sph; ++p) {
                         const SphereHot<F> g = P.sph_hot[p];
                         refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
                     }
@@ -963,28 +1149,63 @@ template <typename F> __global__ void __launch_bounds__(kBlockThreads) tail_kern
                 done = shade<F>(P, lb, path, rng, radiance);
             }
             if (done) {
-                acc = vadd<F>(acc, radiance);
+                acc = single ? radiance : vadd<F>(acc, radiance); // units k >= 1 deliver the sample itself
                 s_cur += 1;
                 need_ray = true;
+                if (s_cur >= s_end) {
+                    if (sub == 0) {
+                        F *o = P.tail_rad + (size_t)out_index * 3;
+                        o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+                    }
+                    have = false;
+                }
             }
         }
-        if (lane == 0) {
-            F *o = task_slot<F>(P, it.task);
-            o[0] = acc.x;
-            o[1] = acc.y;
-            o[2] = acc.z;
+    }
+    if (P.collect_stats) {
+        // one count per group, summed over the wave's groups by lane 0
+        uint32_t wave_segments = sub == 0 ? n_segments : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wave_segments += __shfl_xor(wave_segments, off);
+        if (lane == 0 && wave_segments) {
+            atomicAdd(&P.counters[0], (unsigned long long)wave_segments);
+            atomicAdd(&P.counters[3], (unsigned long long)wave_segments); // the tail kernel tests every primitive
         }
     }
-    if (P.collect_stats && lane == 0 && n_segments) {
-        atomicAdd(&P.counters[0], (unsigned long long)n_segments);
-        atomicAdd(&P.counters[3], (unsigned long long)n_segments); // the tail kernel tests every primitive
-    }
 #ifdef RRTX_DIAG
-    if (lane == 0) {
-        unsigned long long *d = P.diag + (size_t)(65536 + wave_id) * 8;
-        d[0] = diag_t0, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = n_segments, d[4] = n_items;
+    {
+        uint32_t wave_segments = sub == 0 ? n_segments : 0u;
+        for (int off = 32; off >= 1; off >>= 1) wave_segments += __shfl_xor(wave_segments, off);
+        if (lane == 0) {
+            const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+            unsigned long long *d = P.diag + (size_t)(65536 + wid) * 8;
+            d[0] = diag_t0, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = wave_segments, d[4] = P.tail_count[0];
+        }
     }
 #endif
+}
+
+// Adds the tail kernel's results of each parked item in sample order (the order rrt.cu:115 adds them)
+// and stores the task's partial sum.  One thread per item.
+template <typename F> __global__ void __launch_bounds__(256) tail_sum_kernel(const KernelParams<F> P)
+{
+    const uint32_t n_items = *P.tail_count;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += gridDim.x * blockDim.x) {
+        const TailItem<F> it = P.tail_items[item];
+        int px_i, px_j, s_first, s_end;
+        task_decode<F>(P, it.task, px_i, px_j, s_first, s_end);
+        const int remaining = s_end - it.s_cur;
+        const int units = remaining < kTailSplit ? remaining : kTailSplit;
+        const F *r = P.tail_rad + (size_t)item * kTailSplit * 3;
+        F ax = r[0], ay = r[1], az = r[2]; // unit 0 continued the item's partial sum
+        for (int k = 1; k < units; ++k) {
+            ax = ax + r[3 * k + 0];
+            ay = ay + r[3 * k + 1];
+            az = az + r[3 * k + 2];
+        }
+        F *o = task_slot<F>(P, it.task);
+        o[0] = ax, o[1] = ay, o[2] = az;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1054,14 +1275,28 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
 }
 
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
-// number of devices).  Only launched when chunks_per_pixel > 1.
-template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, uint32_t n_values, int chunks_per_pixel)
+// number of devices).  Launched unless every pixel is a single task.
+template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, FinalizeShape S)
 {
-    // one thread per (pixel, channel) value: n_values = pixels * 3; partial is [chunk][pixel][3]
+    // one thread per (pixel, channel) value
+    const uint32_t n_values = S.n_pixels * 3u, n_chunked = S.taper_pixel * 3u, n_tapered = n_values - n_chunked;
+    const F *const samples = partial + (size_t)n_chunked * S.chunks_per_pixel;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
-        const F *p = partial + v;
         F s = 0;
-        for (int c = 0; c < chunks_per_pixel; ++c) s = s + p[(size_t)c * n_values];
+        if (v < n_chunked) {
+            const F *p = partial + v;
+            for (int c = 0; c < S.chunks_per_pixel; ++c) s = s + p[(size_t)c * n_chunked];
+        }
+        else {
+            // the sums a chunk task would have formed: 0 + s0 + s1 + ... per chunk, then chunk by chunk
+            const F *p = samples + (v - n_chunked);
+            for (int first = 0; first < S.spp; first += S.chunk) {
+                const int end = first + S.chunk < S.spp ? first + S.chunk : S.spp;
+                F cs = 0;
+                for (int k = first; k < end; ++k) cs = cs + p[(size_t)k * n_tapered];
+                s = s + cs;
+            }
+        }
         fb[v] = s;
     }
 }
@@ -1094,17 +1329,27 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
     hipLaunchKernelGGL(primary_lists_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, plist);
     return hipGetLastError();
 }
+#ifndef RRTX_TAIL_GROUP
+#define RRTX_TAIL_GROUP 16 // lanes per ray in the tail kernel
+#endif
 template <typename F> hipError_t launch_tail(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(tail_kernel<F>, dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    const size_t lds = (size_t)P.n_sph_padded * sizeof(SphereHot<F>);
+    if (lds <= (size_t)kLdsSceneBytes)
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, true>), dim3(grid_blocks), dim3(kBlockThreads), lds, stream, P);
+    else
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, false>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tail_sum_kernel<F>, dim3(256), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
-template <typename F> hipError_t launch_finalize(const F *partial, F *fb, uint32_t n_values, int chunks_per_pixel, hipStream_t stream)
+template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const FinalizeShape &S, hipStream_t stream)
 {
-    int blocks = (int)((n_values + 255u) / 256u);
+    int blocks = (int)((S.n_pixels * 3u + 255u) / 256u);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, n_values, chunks_per_pixel);
+    hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, S);
     return hipGetLastError();
 }
 template <typename F> hipError_t render_occupancy(bool filter, int lds_mode, int n_sph_padded, int *blocks_per_cu)
@@ -1124,8 +1369,8 @@ template hipError_t launch_primary_lists<float>(const KernelParams<float> &, uin
 template hipError_t launch_primary_lists<double>(const KernelParams<double> &, uint16_t *, hipStream_t);
 template hipError_t launch_tail<float>(const KernelParams<float> &, int, hipStream_t);
 template hipError_t launch_tail<double>(const KernelParams<double> &, int, hipStream_t);
-template hipError_t launch_finalize<float>(const float *, float *, uint32_t, int, hipStream_t);
-template hipError_t launch_finalize<double>(const double *, double *, uint32_t, int, hipStream_t);
+template hipError_t launch_finalize<float>(const float *, float *, const FinalizeShape &, hipStream_t);
+template hipError_t launch_finalize<double>(const double *, double *, const FinalizeShape &, hipStream_t);
 template hipError_t render_occupancy<float>(bool, int, int, int *);
 template hipError_t render_occupancy<double>(bool, int, int, int *);
 

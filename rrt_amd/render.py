@@ -103,7 +103,7 @@ class Rrt:
     threads_x, threads_y) and render(scene) -> framebuffer (row 0 = bottom, un-normalised sums)."""
 
     def __init__(self, image_width, image_height, samples_per_pixel, max_depth, use_bvh=True, threads_x=8, threads_y=8, *, fp64=False, device=0, seed=1984,
-                 sample_chunk=0, shard_rank=0, shard_count=1, tile_rows=4, collect_stats=True, exact_scan=False, flags=0, handoff_lanes=0, handoff_iters=0, list_passes=0):
+                 sample_chunk=0, shard_rank=0, shard_count=1, tile_rows=4, collect_stats=True, exact_scan=False, flags=0, handoff_lanes=0, handoff_iters=0, list_passes=0, taper_samples=0):
         p = _lib.Params()
         p.image_width, p.image_height = int(image_width), int(image_height)
         p.samples_per_pixel, p.max_depth = int(samples_per_pixel), int(max_depth)
@@ -119,6 +119,7 @@ class Rrt:
         p.handoff_lanes = int(handoff_lanes)
         p.handoff_iters = int(handoff_iters)
         p.list_passes = int(list_passes)
+        p.taper_samples = int(taper_samples)
         self.params = p
         self.fp64 = bool(fp64)
         self._ctx = C.c_void_p()

@@ -297,6 +297,30 @@ def test_hand_off_thresholds_do_not_change_the_image(gpu):
         r.close()
 
 
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_single_sample_taper_does_not_change_the_image(gpu, fp64):
+    """The last `taper_samples` samples of the queue are dealt one by one and summed chunk-wise by
+    finalize_kernel: pure scheduling.  -1 = every task is a chunk, huge = every task is one sample."""
+    w, h, spp = 96, 64, 21
+    sc = gpu.Scene(SCENES["final"], w, h, fp64=fp64)
+    for chunk in (8, 5, -1):
+        want, _ = Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp if chunk < 0 else chunk)
+        for taper in (-1, 1, spp * w * 3 + 7, w * h * spp // 2, 2**31 - 1):
+            r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=chunk, taper_samples=taper)
+            assert np.array_equal(r.render(sc), want), (chunk, taper)
+            r.close()
+    # sharded: each shard tapers its own queue
+    want, _ = Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+    got = np.zeros_like(want)
+    for rank in range(3):
+        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, shard_rank=rank, shard_count=3, tile_rows=4, taper_samples=w * 5 * spp + 3)
+        part = r.render(sc)
+        rows = r.shard_rows()
+        got[rows] = part[rows]
+        r.close()
+    assert np.array_equal(got, want)
+
+
 def _write_scene(path, spheres, cam="camera 0 1 6 0 0 0 0 1 0 40 0.05 6"):
     lines = [cam, "material a lambertian 0.7 0.4 0.3", "material g dielectric 1.5", "material m metal 0.8 0.8 0.9 0.1"]
     lines += ["sphere %r %r %r %r %s" % s for s in spheres]

@@ -154,3 +154,12 @@ def test_cli_argument_errors_exit_like_the_reference(binary, tmp_path):
     bad.write_text("camera 0 0 5 0 0 0 0 1 0 30 0.1 5\nmaterial m plastic 1 1 1\n")
     r = subprocess.run([exe, "-i", str(bad)], capture_output=True)
     assert r.returncode == 3 and b"unknown material type: plastic" in r.stderr
+
+
+def test_fast_division_by_launch_constants_is_exact(tmp_path):
+    """task_decode divides by W, tile_rows, spp and chunks_per_pixel with a multiply-high (rrtx_device.h
+    make_fastdiv); the host check compares it with `/` for n < 2^31 over ~100M (n, d) pairs."""
+    exe = tmp_path / "fastdiv_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "fastdiv_check.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert " bad 0" in out, out

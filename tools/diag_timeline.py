@@ -37,3 +37,10 @@ seg = r.stats["segments"]
 ideal_iters = seg / 64.0 / len(m)
 per_it = np.median(dur / m[:, 3])
 print("segments %d -> ideal iterations per wave %.1f x %.2f us = %.1f us; lane efficiency overall %.3f" % (seg, ideal_iters, per_it, ideal_iters * per_it, seg / 64.0 / m[:, 3].sum()))
+if os.environ.get("DIAG_LATE"):
+    order = np.argsort(m[:, 1])[::-1][:24]
+    idx = np.nonzero(buf[:65536, 0] > 0)[0]
+    for o in order:
+        print("wave %5d (block %4d) dry %.1f exit %.1f iters %d after-dry %d  us/iter %.2f | last pull at %.1f us, iteration %d, base %d of %d, pulls %d" % (idx[o], idx[o] // 4, us(m[o:o+1, 1])[0], us(m[o:o+1, 2])[0], m[o, 3], m[o, 4], dur[o] / m[o, 3], us(m[o:o+1, 5])[0], int(m[o, 6]) & 0xFFFFFFFF, m[o, 7], r.stats.get("total_tasks", 0), int(m[o, 6]) >> 32))
+    h, edges = np.histogram(us(dry[:, 1]), bins=20)
+    print("dry-time histogram:", list(zip(edges[:-1].round(0).tolist(), h.tolist())))
