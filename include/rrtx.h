@@ -126,8 +126,8 @@ typedef struct rrtx_params {
                                           passes; 0 = default (3), -1 = none                    */
     int32_t taper_samples;             /* tuning: this many samples at the end of the work queue are
                                           handed out one by one instead of in chunks (rounded up to
-                                          whole pixels); 0 = automatic, -1 = none.  Scheduling only:
-                                          the image does not depend on it                        */
+                                          whole pixels); 0 = automatic (currently none), -1 = none.
+                                          Scheduling only: the image does not depend on it       */
     int32_t reserved[1];
 } rrtx_params;
 

@@ -594,13 +594,13 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     if (c->p.fp64) {
         KernelParams<double> P = make_params<double>(c, out);
         RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(launch_tail<double>(P, c->tail_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
         if (c->use_partial) RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, shape, st));
     }
     else {
         KernelParams<float> P = make_params<float>(c, out);
         RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(launch_tail<float>(P, c->tail_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
         if (c->use_partial) RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, shape, st));
     }
     RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));

@@ -21,7 +21,10 @@ namespace rrtx {
 constexpr int kSphereUnroll = 8;  // tests per straight-line block (fp32; fp64 uses half)
 constexpr int kSpherePad = 16;    // the sphere tables are padded to a multiple of this (two blocks)
 constexpr int kLdsSceneBytes = 48 * 1024; // largest scan table mirrored in LDS
-constexpr int kCandCap = 16;      // candidate slots per lane (LDS), flushed when nearly full
+#ifndef RRTX_CAND_CAP
+#define RRTX_CAND_CAP 16
+#endif
+constexpr int kCandCap = RRTX_CAND_CAP;      // candidate slots per lane (LDS), flushed when nearly full
 #ifndef RRTX_BLOCK_THREADS
 #define RRTX_BLOCK_THREADS 256
 #endif
@@ -145,10 +148,12 @@ struct FinalizeShape {
     int32_t chunks_per_pixel, chunk, spp;
 };
 
-// Samples handed out as single-sample tasks at the end of the queue, per compute unit (automatic
-// setting): about 2 ms of the chip's work on the headline scene, enough for every chunk task to have
-// finished before the queue runs dry.
-constexpr int64_t kTaperSamplesPerCu = 2048 * 24;
+// Samples handed out as single-sample tasks at the end of the queue, per compute unit, when
+// rrtx_params.taper_samples is 0 (automatic).  Measured on final.txt 1200x800 with the queue-over flag,
+// pool parking and the unit split of parked items in place: none is best from spp 48 up (spp 504: 78.6 ms
+// without, 79.6 ms with 2048 * 24 per CU: the cursor becomes the bottleneck in cheap regions of the
+// frame); only very short launches gain (spp 8: 2.9 vs 3.2 ms).  So: off unless asked for.
+constexpr int64_t kTaperSamplesPerCu = 0;
 
 } // namespace rrtx
 

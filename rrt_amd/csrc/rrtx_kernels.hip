@@ -361,7 +361,8 @@ template <typename F, typename PP> RRTX_DEV void task_decode(const PP &P, uint32
 
 // Where a task's partial sum goes.  Chunked pixels: chunk-major [chunk][pixel < taper_pixel][3], so that
 // finalize_kernel reads consecutive pixels with consecutive threads (with one chunk per pixel and no
-// taper this IS the local frame).  Single-sample tasks follow, sample-major [sample][pixel - taper_pixel][3].
+// taper this IS the local frame).  Single-sample tasks follow in task order, [pixel - taper_pixel][sample][3]:
+// the lanes of a wave hold consecutive samples of a pixel, so their stores are contiguous.
 template <typename F, typename PP> RRTX_DEV F *task_slot(const PP &P, uint32_t task)
 {
     if (task < P.taper_task_base) {
@@ -369,11 +370,7 @@ template <typename F, typename PP> RRTX_DEV F *task_slot(const PP &P, uint32_t t
         const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
         return P.out + ((size_t)c * (size_t)P.taper_pixel + q) * 3;
     }
-    const uint32_t t = task - P.taper_task_base;
-    const uint32_t dq = fdiv(t, P.div_spp);
-    const uint32_t sidx = t - dq * (uint32_t)P.spp;
-    const size_t n_tapered = (size_t)P.local_rows * (size_t)P.W - (size_t)P.taper_pixel;
-    return P.out + ((size_t)P.taper_task_base + (size_t)sidx * n_tapered + dq) * 3;
+    return P.out + (size_t)task * 3;
 }
 
 // camera ray of sample `s` of pixel (i, j): rrt.cu:112-114, camera.h:31-38
@@ -483,6 +480,37 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
     path.d = new_d; // time unchanged (material.h:29)
     path.depth += 1;
     return path.depth >= P.max_depth; // rrt.cu:47,78: radiance stays 0
+}
+
+// Per-segment half of the conservative scan filter (see the render kernel's phase 1 and DESIGN.md
+// "Conservative scan filter"): with n = d/|d|, u = c.n, s = o.n,
+//   disc/|d|^2 = u^2 + 2(o - s n).c + (s^2 - |o|^2) + (r^2 - |c|^2);
+// per sphere the host stores c and thr = |c|^2 - r^2 - K eps (|c|^2 + r^2) rounded down, and
+//   candidate  <=>  not (u^2 + b.c + g < thr).
+// Rays with non-finite or extreme components get g = +inf: everything is a candidate, the exact test decides.
+template <typename F> struct FilterRay {
+    F nx, ny, nz, bx, by, bz, g;
+};
+template <typename F> RRTX_DEV FilterRay<F> make_filter_ray(const Path<F> &path, F a)
+{
+    FilterRay<F> r = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
+    const F o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
+    if (a >= Limits<F>::tiny() && a <= Limits<F>::big() && o2 <= Limits<F>::big()) {
+        const F inv = (F)1 / fsqrt(a);
+        r.nx = path.d.x * inv, r.ny = path.d.y * inv, r.nz = path.d.z * inv;
+        const F sdot = ffma(path.o.z, r.nz, ffma(path.o.y, r.ny, path.o.x * r.nx));
+        r.bx = (F)2 * ffma(-sdot, r.nx, path.o.x);
+        r.by = (F)2 * ffma(-sdot, r.ny, path.o.y);
+        r.bz = (F)2 * ffma(-sdot, r.nz, path.o.z);
+        r.g = ffma(Limits<F>::margin(), o2, ffma(sdot, sdot, -o2));
+    }
+    return r;
+}
+template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy, F cz)
+{
+    const F uu = ffma(cz, r.nz, ffma(cy, r.ny, cx * r.nx));
+    const F w = ffma(r.bz, cz, ffma(r.by, cy, ffma(r.bx, cx, r.g)));
+    return ffma(uu, uu, w);
 }
 
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
@@ -805,21 +833,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
             //   Per segment: n, b = 2(o - s n), g = s^2 - |o|^2 + K eps |o|^2.  Per sphere (SGPRs):
             //   c and thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), rounded down on the host.
             //   candidate  <=>  not (u^2 + b.c + g < thr).   Phase 2 then applies the exact test.
-            F nx = 0, ny = 0, nz = 0, bx = 0, by = 0, bz = 0, g = Limits<F>::inf();
-            if (FILTER) {
-                const F o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
-                // rays with non-finite or extreme components take the always-candidate route (g = +inf):
-                // phase 2 is exact, so they stay correct, merely slow
-                if (a >= Limits<F>::tiny() && a <= Limits<F>::big() && o2 <= Limits<F>::big()) {
-                    const F inv = (F)1 / fsqrt(a);
-                    nx = path.d.x * inv, ny = path.d.y * inv, nz = path.d.z * inv;
-                    const F sdot = ffma(path.o.z, nz, ffma(path.o.y, ny, path.o.x * nx));
-                    bx = (F)2 * ffma(-sdot, nx, path.o.x);
-                    by = (F)2 * ffma(-sdot, ny, path.o.y);
-                    bz = (F)2 * ffma(-sdot, nz, path.o.z);
-                    g = ffma(Limits<F>::margin(), o2, ffma(sdot, sdot, -o2));
-                }
-            }
+            FilterRay<F> fr = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
+            if (FILTER) fr = make_filter_ray<F>(path, a); // extreme rays take the always-candidate route: phase 2 is exact
             constexpr int kUnroll = SphereUnroll<F>::value;
             // one straight-line block of N tests; FROM_LDS selects the operand source
             auto scan_block = [&](int k0, auto from_lds_c, auto n_c) {
@@ -843,9 +858,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                     constexpr int u = decltype(uc)::value;
                     const F cx = bcx[u], cy = bcy[u], cz = bcz[u], r2 = bw[u];
                     if (FILTER) {
-                        const F uu = ffma(cz, nz, ffma(cy, ny, cx * nx));
-                        const F w = ffma(bz, cz, ffma(by, cy, ffma(bx, cx, g)));
-                        push_if_not_less<u, FROM_LDS>(ffma(uu, uu, w), r2, cnt, my_cand_lds, my_cand, k0); // the r2 slot holds thr
+                        push_if_not_less<u, FROM_LDS>(filter_value<F>(fr, cx, cy, cz), r2, cnt, my_cand_lds, my_cand, k0); // the r2 slot holds thr
                     }
                     else {
                         const F ocx = path.o.x - cx, ocy = path.o.y - cy, ocz = path.o.z - cz;
@@ -967,17 +980,24 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
 // remain, one per group at the end) and dealt to the groups as they finish, as the render kernel deals
 // tasks to lanes.
 // ---------------------------------------------------------------------------------------------
-template <typename F, int G, bool LDS> __global__ void __launch_bounds__(kBlockThreads) tail_kernel(const KernelParams<F> P)
+template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bounds__(kBlockThreads) tail_kernel(const KernelParams<F> P)
 {
     // the sphere table is read from a copy in LDS when it fits (the scan is a chain of dependent loads
     // otherwise: ~1 us each from L2 under load)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    const SphereHot<F> *sph_tab = P.sph_hot;
+    const SphereHot<F> *sph_tab = FILTER ? P.sph_filter : P.sph_hot;
+    const F *r2_tab = &P.sph_hot[0].r2; // FILTER: r*r of the candidates (the centres are in the filter records)
+    int r2_stride = 4;
     if (LDS) {
         SphereHot<F> *const copy = (SphereHot<F> *)dyn_lds;
-        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) copy[i] = P.sph_hot[i];
+        F *const r2_copy = (F *)(copy + P.n_sph_padded);
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) {
+            copy[i] = sph_tab[i];
+            if (FILTER) r2_copy[i] = P.sph_hot[i].r2;
+        }
         __syncthreads();
         sph_tab = copy;
+        if (FILTER) r2_tab = r2_copy, r2_stride = 1;
     }
     constexpr uint32_t kGroups = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -1092,15 +1112,28 @@ template <typename F, int G, bool LDS> __global__ void __launch_bounds__(kBlockT
                 const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
                 const bool sane = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big();
                 if (sane) {
-                    // (padding records have r*r = -inf: discriminant -inf, never a hit)
+                    // FILTER: the conservative 7-FMA test of the render kernel's phase 1 first, the exact
+                    // test (record from HBM) only for its candidates; otherwise the exact test throughout.
+                    // (padding records: thr = +inf / r*r = -inf, never a hit)
+                    FilterRay<F> fr = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
+                    if (FILTER) fr = make_filter_ray<F>(path, a);
                     constexpr int U = 4; // loads in flight per lane
                     for (int p0 = sub; p0 < n_sph_pad; p0 += U * G) {
                         SphereHot<F> g[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) g[u] = sph_tab[p0 + u * G < n_sph_pad ? p0 + u * G : 0];
 #pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            if (p0 + u * G < n_sph_pad) refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, g[u].r2, path, a, t_min, p0 + u * G, lb);
+                        for (int u = 0; u < U; ++u) {
+                            const int idx = p0 + u * G;
+                            if (idx >= n_sph_pad) continue;
+                            if (FILTER) {
+                                if (!(filter_value<F>(fr, g[u].cx, g[u].cy, g[u].cz) < g[u].r2)) { // the r2 slot holds thr
+                                    refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, r2_tab[idx * r2_stride], path, a, t_min, idx, lb);
+                                }
+                            }
+                            else
+                                refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, g[u].r2, path, a, t_min, idx, lb);
+                        }
                     }
                     for (int q = sub; q < n_msph; q += G) {
                         const MovingSphereRec<F> ms = P.msph[q];
@@ -1279,7 +1312,7 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
 template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, FinalizeShape S)
 {
     // one thread per (pixel, channel) value
-    const uint32_t n_values = S.n_pixels * 3u, n_chunked = S.taper_pixel * 3u, n_tapered = n_values - n_chunked;
+    const uint32_t n_values = S.n_pixels * 3u, n_chunked = S.taper_pixel * 3u;
     const F *const samples = partial + (size_t)n_chunked * S.chunks_per_pixel;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
         F s = 0;
@@ -1289,11 +1322,12 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
         }
         else {
             // the sums a chunk task would have formed: 0 + s0 + s1 + ... per chunk, then chunk by chunk
-            const F *p = samples + (v - n_chunked);
+            const uint32_t dq = (v - n_chunked) / 3u, ch = (v - n_chunked) - dq * 3u;
+            const F *p = samples + ((size_t)dq * (size_t)S.spp) * 3 + ch;
             for (int first = 0; first < S.spp; first += S.chunk) {
                 const int end = first + S.chunk < S.spp ? first + S.chunk : S.spp;
                 F cs = 0;
-                for (int k = first; k < end; ++k) cs = cs + p[(size_t)k * n_tapered];
+                for (int k = first; k < end; ++k) cs = cs + p[(size_t)k * 3];
                 s = s + cs;
             }
         }
@@ -1330,15 +1364,20 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
     return hipGetLastError();
 }
 #ifndef RRTX_TAIL_GROUP
-#define RRTX_TAIL_GROUP 16 // lanes per ray in the tail kernel
+#define RRTX_TAIL_GROUP 8 // lanes per ray in the tail kernel (measured on final.txt spp 48: 32 -> 1.82, 16 -> 1.33, 8 -> 1.18, 4 -> 1.17 ms)
 #endif
-template <typename F> hipError_t launch_tail(const KernelParams<F> &P, int grid_blocks, hipStream_t stream)
+template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filter, int grid_blocks, hipStream_t stream)
 {
-    const size_t lds = (size_t)P.n_sph_padded * sizeof(SphereHot<F>);
-    if (lds <= (size_t)kLdsSceneBytes)
-        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, true>), dim3(grid_blocks), dim3(kBlockThreads), lds, stream, P);
+    const size_t lds = (size_t)P.n_sph_padded * (sizeof(SphereHot<F>) + (filter ? sizeof(F) : 0));
+    const bool in_lds = lds <= (size_t)kLdsSceneBytes;
+    if (filter && in_lds)
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, true, true>), dim3(grid_blocks), dim3(kBlockThreads), lds, stream, P);
+    else if (filter)
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, false, true>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    else if (in_lds)
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, true, false>), dim3(grid_blocks), dim3(kBlockThreads), lds, stream, P);
     else
-        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, false>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+        hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, false, false>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tail_sum_kernel<F>, dim3(256), dim3(256), 0, stream, P);
@@ -1367,8 +1406,8 @@ template hipError_t launch_render<float>(const KernelParams<float> &, bool, int,
 template hipError_t launch_render<double>(const KernelParams<double> &, bool, int, int, hipStream_t);
 template hipError_t launch_primary_lists<float>(const KernelParams<float> &, uint16_t *, hipStream_t);
 template hipError_t launch_primary_lists<double>(const KernelParams<double> &, uint16_t *, hipStream_t);
-template hipError_t launch_tail<float>(const KernelParams<float> &, int, hipStream_t);
-template hipError_t launch_tail<double>(const KernelParams<double> &, int, hipStream_t);
+template hipError_t launch_tail<float>(const KernelParams<float> &, bool, int, hipStream_t);
+template hipError_t launch_tail<double>(const KernelParams<double> &, bool, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, const FinalizeShape &, hipStream_t);
 template hipError_t launch_finalize<double>(const double *, double *, const FinalizeShape &, hipStream_t);
 template hipError_t render_occupancy<float>(bool, int, int, int *);
