@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over the workload: render the 1200x800 spp=500 depth=50 fp32 frame
-of scenes/final.txt (scene tables already resident in HBM, framebuffer left in HBM) and, for N > 1,
-the one gather of the row-tile shards to rank 0 over RCCL.  N > 1 shards the SAME frame
-("scaling": "strong"); the image is bit-identical for every N.
+A step = one pass of the hot path over the workload: render the 1200x800 depth=50 fp32 frame of
+scenes/final.txt (scene tables already resident in HBM, framebuffer left in HBM) and, for N > 1, the
+one gather of the row-tile shards to rank 0 over RCCL.  N = 1 is BASELINE.json's configuration, spp = 500.
+N > 1 keeps the work per GPU fixed ("scaling": "weak", as the frame is a partitioned path): the same
+frame, row tiles dealt round-robin to the ranks, at spp = 500 x N — every rank traces 480 M samples, as
+BASELINE.json's own 8-GPU configuration scales the job (3840x2160 spp 1000) rather than splitting the
+1-GPU one.  `--strong` shards the spp = 500 frame instead (9.7 ms of work per GPU at N = 8; DESIGN.md has
+the fixed per-launch cost that then shows).  The image is bit-identical for every N and tile size.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   roofline     - logical primitive-read roofline of the render kernel: algorithmic bytes per launch
@@ -98,7 +102,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (non-headline runs only)")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (non-headline runs only); default 500 x N (weak scaling)")
+    ap.add_argument("--strong", action="store_true", help="N > 1: shard the spp = 500 frame (fixed total work) instead of scaling spp with N")
     ap.add_argument("--tile-rows", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -128,6 +133,9 @@ def main():
             dist.init_process_group(backend)
 
     from rrt_amd.dist import ShardedRenderer
+
+    if args.spp <= 0:
+        args.spp = SPP if args.strong else SPP * world
 
     sr = ShardedRenderer(SCENE, WIDTH, HEIGHT, args.spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=torch.device("cuda", device_index), collect_stats=True)
 
@@ -180,7 +188,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
