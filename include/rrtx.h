@@ -146,7 +146,8 @@ typedef struct rrtx_params {
 /* Send camera rays through the full scan too instead of their pixel's candidate list (A/B switch). */
 #define RRTX_FLAG_NO_PRIMARY_LISTS 16
 /* Test mode: every camera ray intersected through its list is also scanned sequentially on its
- * lane; rrtx_stats.list_mismatches counts the rays for which the two disagree (must stay 0). */
+ * lane; rrtx_stats.list_mismatches counts the rays for which the two disagree (must stay 0).
+ * With use_bvh the same is done for every segment resolved through the acceleration grid. */
 #define RRTX_FLAG_VERIFY_LISTS 32
 
 typedef struct rrtx_stats {
@@ -155,7 +156,7 @@ typedef struct rrtx_stats {
     double kernel_ms_sum;    /* the same, summed over the `renders` launches since the
                                 previous rrtx_collect / rrtx_render                          */
     int32_t renders;
-    int32_t reserved0;
+    int32_t accel_cells;     /* use_bvh: cells of the acceleration grid in use, 0 = the list is scanned   */
     double wall_ms;          /* host wall time of the last blocking render call              */
     uint64_t samples;        /* pixels_rendered * spp                                        */
     uint64_t segments;       /* path segments traced (0 unless collect_stats)                */

@@ -60,7 +60,7 @@ class Stats(C.Structure):  # rrtx_stats
         ("kernel_ms", C.c_double),
         ("kernel_ms_sum", C.c_double),
         ("renders", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("accel_cells", C.c_int32),
         ("wall_ms", C.c_double),
         ("samples", C.c_uint64),
         ("segments", C.c_uint64),

@@ -3,9 +3,11 @@
 // create_world kernel or the per-pixel curand state.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -83,6 +85,12 @@ struct rrtx_ctx {
     unsigned long long *d_counters = nullptr;
     void *d_partial = nullptr; // [total_tasks][3] unless every pixel is a single task
     uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
+    // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
+    bool accel = false;
+    uint32_t *d_grid_cell_start = nullptr, *d_grid_always = nullptr;
+    uint16_t *d_grid_cell_prims = nullptr;
+    int n_grid_cells = 0, n_grid_prims = 0, n_always = 0;
+    unsigned char grid_bytes[sizeof(GridRec<double>)];
     void *d_tail_items = nullptr; // parked work items (render kernel -> tail kernel)
     void *d_tail_rad = nullptr;   // the results of their work units
     uint32_t *d_tail_units = nullptr;
@@ -124,6 +132,151 @@ template <typename F> void pack_unit(const F v[3], F out[3])
     F len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     F inv = (F)1 / len;
     out[0] = inv * v[0], out[1] = inv * v[1], out[2] = inv * v[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Acceleration grid for use_bvh != 0 (device side: accel_closest_hit).
+//
+// Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2.5 x their median
+// extent); primitives larger than 1.6 cells, spheres smaller than a fiftieth of a cell and all
+// triangles go into the "always" list.  Every gridded primitive is entered into all cells its box,
+// inflated by delta = 0.1 cell, overlaps.  Why that is enough: the reference's discriminant,
+// evaluated in floating point, can be >= 0 only if the ray's line passes within
+// sqrt(r^2 + m) of the centre, m = 32 eps (|o - c|^2 + r^2) (a bound on the rounding error of
+// (oc.d)^2 - |d|^2 (|oc|^2 - r^2) relative to |d|^2; 24 eps by the usual gamma_n accounting), and the
+// root it then reports lies within sqrt(m) of the sphere along the ray.  So with
+// sqrt(r_min^2 + m) - r_min <= delta for every ray that starts within `far` of the grid's centre, a
+// primitive whose test can succeed is always found in a cell the ray's exact line passes through or
+// within delta of — and a 3-D DDA that is off by a few ulps at a cell boundary only ever trades a cell
+// the ray grazes by less than delta for its neighbour.  Rays starting further away take the list scan.
+// The walk stops once the next cell begins more than slack0 + slack1 (|o - centre| + half diagonal)
+// beyond the closest hit, slack1 = 1.5 sqrt(32 eps): the along-ray error of a root.
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const std::vector<SphereCold<F>> &cold, int n_sph, int n_sph_pad, const std::vector<MovingSphereRec<F>> &ms,
+                       int n_msph, int n_tri, const CameraRec<F> &cam, std::vector<uint32_t> &cell_start, std::vector<uint16_t> &cell_prims, std::vector<uint32_t> &always,
+                       GridRec<F> &G)
+{
+    const int msph_base = n_sph_pad, tri_base = n_sph_pad + n_msph;
+    if ((int64_t)tri_base + n_tri >= 65535) return false; // cell lists hold 16-bit primitive indices
+    struct Box {
+        double lo[3], hi[3], r;
+        int idx;
+    };
+    std::vector<Box> boxes;
+    for (int i = 0; i < n_sph; ++i) {
+        Box b;
+        const double cc[3] = {(double)hot[i].cx, (double)hot[i].cy, (double)hot[i].cz}, r = std::fabs((double)cold[i].radius);
+        for (int k = 0; k < 3; ++k) b.lo[k] = cc[k] - r, b.hi[k] = cc[k] + r;
+        b.r = r, b.idx = i;
+        boxes.push_back(b);
+    }
+    for (int i = 0; i < n_msph; ++i) {
+        // centre(tm) = c0 + ((tm - t0) / dt) dc is linear in tm: the hull over the shutter interval is the
+        // hull of its end points (the ray's time is drawn from [time0, time1], camera.h:37)
+        Box b;
+        const double r = std::fabs((double)ms[i].radius);
+        for (int k = 0; k < 3; ++k) b.lo[k] = 1e300, b.hi[k] = -1e300;
+        for (double tm : {(double)cam.time0, (double)cam.time1}) {
+            const double sfrac = (tm - (double)ms[i].t0) / (double)ms[i].dt;
+            for (int k = 0; k < 3; ++k) {
+                const double ck = (double)ms[i].c0[k] + sfrac * (double)ms[i].dc[k];
+                const double pad = 1e-5 * (std::fabs(ck) + r); // the device evaluates the centre in F
+                b.lo[k] = std::min(b.lo[k], ck - r - pad), b.hi[k] = std::max(b.hi[k], ck + r + pad);
+            }
+        }
+        b.r = r, b.idx = msph_base + i;
+        boxes.push_back(b);
+    }
+    if (boxes.size() < 32) return false; // nothing to gain on a handful of primitives
+    std::vector<double> ext;
+    for (const Box &b : boxes) ext.push_back(std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}));
+    std::vector<double> sorted = ext;
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    double cell = 2.5 * sorted[sorted.size() / 2];
+    if (!(cell > 0) || !std::isfinite(cell)) return false;
+
+    for (int attempt = 0; attempt < 8; ++attempt, cell *= 1.6) {
+        always.clear();
+        std::vector<int> gridded;
+        double rmin = 1e300, rmax = 0;
+        for (size_t i = 0; i < boxes.size(); ++i) {
+            if (ext[i] > 1.6 * cell || boxes[i].r < cell / 50)
+                always.push_back((uint32_t)boxes[i].idx);
+            else
+                gridded.push_back((int)i), rmin = std::min(rmin, boxes[i].r), rmax = std::max(rmax, boxes[i].r);
+        }
+        for (int i = 0; i < n_tri; ++i) always.push_back((uint32_t)(tri_base + i));
+        if (always.size() > 48) continue; // a larger cell turns "large" primitives into ordinary ones
+        if (gridded.size() < 32) return false;
+        const double delta = 0.1 * cell;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i : gridded)
+            for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k] - delta), hi[k] = std::max(hi[k], boxes[i].hi[k] + delta);
+        int dims[3];
+        double total = 1;
+        for (int k = 0; k < 3; ++k) {
+            dims[k] = (int)std::ceil((hi[k] - lo[k]) / cell);
+            if (dims[k] < 1) dims[k] = 1;
+            total *= dims[k];
+        }
+        if (total > 262144.0) continue;
+        const double hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
+        // sqrt(rmin^2 + m) - rmin <= delta  <=>  m <= delta^2 + 2 delta rmin,  m = 32 eps (R^2 + rmax^2)
+        const double R2 = (delta * delta + 2 * delta * rmin) / (32 * eps) - rmax * rmax;
+        double far = (R2 > 0 ? std::sqrt(R2) : 0) - hd;
+        const double far_cap = sizeof(F) == 4 ? 1e6 : 1e50;
+        if (far > far_cap) far = far_cap;
+        if (far < 2 * hd) continue; // the grid would not even serve rays that start next to it
+        // fill
+        const int ncell = dims[0] * dims[1] * dims[2];
+        std::vector<uint32_t> count(ncell + 1, 0);
+        auto range = [&](const Box &b, int k, int &a, int &z) {
+            a = (int)std::floor((b.lo[k] - delta - lo[k]) / cell), z = (int)std::floor((b.hi[k] + delta - lo[k]) / cell);
+            a = std::max(a, 0), z = std::min(z, dims[k] - 1);
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i : gridded) {
+                int a[3], z[3];
+                for (int k = 0; k < 3; ++k) range(boxes[i], k, a[k], z[k]);
+                for (int iz = a[2]; iz <= z[2]; ++iz)
+                    for (int iy = a[1]; iy <= z[1]; ++iy)
+                        for (int ix = a[0]; ix <= z[0]; ++ix) {
+                            const int cidx = (iz * dims[1] + iy) * dims[0] + ix;
+                            if (pass == 0)
+                                count[cidx + 1] += 1;
+                            else
+                                cell_prims[count[cidx]++] = (uint16_t)boxes[i].idx;
+                        }
+            }
+            if (pass == 0) {
+                for (int q = 0; q < ncell; ++q) count[q + 1] += count[q];
+                cell_start.assign(count.begin(), count.end());
+                cell_prims.assign(count[ncell], 0);
+                if (count[ncell] > 4000000u) return false;
+            }
+        }
+        // within a cell keep primitive order (not needed for correctness; keeps runs deterministic)
+        for (int q = 0; q < ncell; ++q) std::sort(cell_prims.begin() + cell_start[q], cell_prims.begin() + cell_start[q + 1]);
+        for (int k = 0; k < 3; ++k) {
+            G.gmin[k] = (F)lo[k], G.gmax[k] = (F)(lo[k] + dims[k] * cell);
+            G.cell[k] = (F)cell, G.inv_cell[k] = (F)(1.0 / cell);
+            G.dims[k] = dims[k];
+            G.center[k] = (F)(0.5 * (lo[k] + hi[k]));
+        }
+        G.far2 = (F)(far * far);
+        G.slack = (F)(0.01 * cell);              // slack0
+        G.slack1 = (F)(1.5 * std::sqrt(32 * eps)); // times (|o - centre| + half diagonal)
+        G.half_diag = (F)hd;
+        G.max_steps = dims[0] + dims[1] + dims[2] + 3;
+        if (getenv("RRTX_DEBUG_GRID"))
+            fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, delta %g, rmin %g rmax %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],
+                    cell_prims.size(), always.size(), delta, rmin, rmax, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2]);
+        (void)c;
+        return true;
+    }
+    return false;
 }
 
 template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
@@ -287,6 +440,30 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             for (int k = 0; k < 3; ++k) chk(htri[i].v0[k]), chk(htri[i].e1[k]), chk(htri[i].e2[k]), chk(htri[i].n[k]);
         c->tail_ok = ok;
     }
+    // accelerated closest hit (the reference's -b switches its BVH off, main.cpp:67,90)
+    for (void *p : {(void *)c->d_grid_cell_start, (void *)c->d_grid_cell_prims, (void *)c->d_grid_always})
+        if (p) (void)hipFree(p);
+    c->d_grid_cell_start = c->d_grid_always = nullptr, c->d_grid_cell_prims = nullptr;
+    c->accel = false;
+    if (c->p.use_bvh && c->tail_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN)) {
+        std::vector<uint32_t> cell_start, always;
+        std::vector<uint16_t> cell_prims;
+        GridRec<F> G = {};
+        CameraRec<F> camrec;
+        memcpy(&camrec, c->cam_bytes, sizeof camrec);
+        if (build_grid<F>(c, hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, s->num_triangles, camrec, cell_start, cell_prims, always, G)) {
+            if (cell_prims.empty()) cell_prims.push_back(0);
+            if (always.empty()) always.push_back(0), c->n_always = 0;
+            else c->n_always = (int)always.size();
+            if ((rc = up((void **)&c->d_grid_cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
+            if ((rc = up((void **)&c->d_grid_cell_prims, cell_prims.data(), cell_prims.size() * 2))) return rc;
+            if ((rc = up((void **)&c->d_grid_always, always.data(), always.size() * 4))) return rc;
+            c->n_grid_cells = (int)cell_start.size() - 1;
+            c->n_grid_prims = (int)cell_start.back();
+            memcpy(c->grid_bytes, &G, sizeof G);
+            c->accel = true;
+        }
+    }
     c->n_sph = s->num_spheres;
     c->n_sph_padded = n_pad;
     c->n_msph = s->num_moving_spheres;
@@ -326,6 +503,11 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.tail_items = (TailItem<F> *)c->d_tail_items;
     P.tail_rad = (F *)c->d_tail_rad;
     P.tail_units = c->d_tail_units;
+    if (c->accel) {
+        P.grid_cell_start = c->d_grid_cell_start, P.grid_cell_prims = c->d_grid_cell_prims, P.grid_always = c->d_grid_always;
+        P.n_always = c->n_always, P.n_grid_cells = c->n_grid_cells, P.n_grid_prims = c->n_grid_prims;
+        memcpy(&P.grid, c->grid_bytes, sizeof(GridRec<F>));
+    }
     P.plist = c->d_plist;
     P.list_passes = c->d_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
     P.verify_lists = (c->p.flags & RRTX_FLAG_VERIFY_LISTS) ? 1 : 0;
@@ -480,7 +662,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -507,7 +689,7 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     // persistent grid: fill the chip once with the kernel variant this scene selects; never more
     // blocks than there are task batches
     int bpc = 0;
-    RRTX_HIP(c->p.fp64 ? render_occupancy<double>(c->use_filter, c->lds_mode, c->n_sph_padded, &bpc) : render_occupancy<float>(c->use_filter, c->lds_mode, c->n_sph_padded, &bpc));
+    RRTX_HIP(c->p.fp64 ? render_occupancy<double>(make_params<double>(c, nullptr), c->use_filter, c->lds_mode, &bpc) : render_occupancy<float>(make_params<float>(c, nullptr), c->use_filter, c->lds_mode, &bpc));
     c->blocks_per_cu = bpc < 1 ? 1 : bpc;
     int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
     const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
@@ -549,7 +731,7 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         c->d_tail_units = nullptr;
     }
     c->tail_capacity = 0;
-    if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
+    if (c->tail_ok && !c->accel && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) { // (an accelerated segment is cheap enough for waves to finish their own paths)
         const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
         c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
         c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
@@ -653,6 +835,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->grid_blocks = c->grid_blocks;
         stats->block_threads = kBlockThreads;
         stats->sample_chunk = c->chunk;
+        stats->accel_cells = c->accel ? c->n_grid_cells : 0;
         stats->local_rows = c->local_rows;
         stats->scan_filter = c->use_filter ? 1 : 0;
     }

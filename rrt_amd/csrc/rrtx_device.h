@@ -89,6 +89,21 @@ template <typename F> struct TailItem {
     F o[3], d[3], tm, atten[3];
 };
 
+// Acceleration grid (use_bvh != 0; DESIGN.md "Accelerated closest hit").  A uniform grid over the
+// boxes of all primitives that are not much larger than a cell; the few that are (the ground sphere)
+// sit in an "always" list tested for every segment.  Cell c lists primitives cell_start[c] ..
+// cell_start[c + 1] of cell_prims (unified primitive indices).
+template <typename F> struct GridRec {
+    F gmin[3], gmax[3];  // box of the grid
+    F cell[3], inv_cell[3];
+    int32_t dims[3];
+    F center[3];
+    F far2;              // rays starting further than sqrt(far2) from `center` take the list scan (their
+                         // exact tests are too inaccurate for the inflation the cells were built with)
+    F slack, slack1, half_diag; // the walk continues slack + slack1 (|o - center| + half_diag) world units beyond the closest hit so far
+    int32_t max_steps;   // dims[0] + dims[1] + dims[2] + 3
+};
+
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,
 // L = ceil(log2 d), shift = L - 1; Granlund & Montgomery).  A runtime udiv costs ~40 VALU instructions
 // and the task decoding needs several per camera ray.
@@ -137,6 +152,12 @@ template <typename F> struct KernelParams {
     uint32_t *tail_units;    // work units of the parked items: item << 3 | unit
     F *tail_rad;             // [item][kTailSplit][3] results of the units
     unsigned long long *diag; // RRTX_DIAG builds only (timing stamps), otherwise unused
+    // accelerated closest hit (all null / 0 when the list scan is used)
+    const uint32_t *grid_cell_start; // [cells + 1]
+    const uint16_t *grid_cell_prims;
+    const uint32_t *grid_always;
+    int32_t n_always, n_grid_cells, n_grid_prims;
+    GridRec<F> grid;
     const uint16_t *plist;   // camera-ray candidate lists [local pixel][kPlistStride], or nullptr
     int32_t list_passes;     // 0 = every segment goes through the scan
     int32_t verify_lists;    // test mode: counters[2] counts camera rays whose list hit differs from the full scan

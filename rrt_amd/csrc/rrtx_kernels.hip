@@ -482,6 +482,153 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
     return path.depth >= P.max_depth; // rrt.cu:47,78: radiance stays 0
 }
 
+// ---------------------------------------------------------------------------------------------
+// Accelerated closest hit (the reference's counterpart is its BVH, bvh.h:167-175).
+//
+// The sequential scan's answer is order-independent for finite rays: primitive p offers the root
+// t_p = (near >= t_min ? near : far) if that is >= t_min (sphere.h:43-48; triangle: its t, triangle.h:63),
+// and the winner is the smallest t_p — at equal t the LAST sphere-like primitive (root == t_max is
+// accepted), while a triangle never displaces an equal t (strict <), so the FIRST triangle wins and
+// any sphere beats it.  consider() applies exactly that order to candidates arriving in any order,
+// so it suffices to run the exact test on a superset of the primitives whose test can succeed: the
+// "always" list, then the cells of a uniform grid the ray walks through front to back (3-D DDA),
+// stopping `slack` beyond the closest hit so far.  The cells were filled with boxes inflated by far
+// more than the exact test's error for rays that start within sqrt(far2) of the grid (DESIGN.md has
+// the bound); rays with non-finite or absurd components — and the few distant rays that could still
+// touch the grid — report false and take the list scan.  Returns true when `best` is final.
+// ---------------------------------------------------------------------------------------------
+template <typename F> RRTX_DEV void consider(F t, int idx, int tri_base, HitInfo<F> &best)
+{
+    const int r = idx < tri_base ? idx : -idx - 1, br = best.idx < tri_base ? best.idx : -best.idx - 1;
+    if (t < best.t || (t == best.t && r > br)) {
+        best.t = t;
+        best.idx = idx;
+    }
+}
+template <typename F> RRTX_DEV void sphere_unordered(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, int tri_base, HitInfo<F> &best)
+{
+    // sphere.h:33-49 without the dependence on the scan order (see above)
+    const F ocx = p.o.x - cx, ocy = p.o.y - cy, ocz = p.o.z - cz;
+    const F half_b = ocx * p.d.x + ocy * p.d.y + ocz * p.d.z;
+    const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+    const F disc = half_b * half_b - a * c;
+    if (disc < 0) return;
+    const F sq = fsqrt(disc);
+    F root = (-half_b - sq) / a;
+    if (root < t_min) {
+        root = (-half_b + sq) / a;
+        if (root < t_min) return;
+    }
+    consider<F>(root, idx, tri_base, best);
+}
+template <typename F, typename PP, typename HotTab> RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path<F> &path, F a, F t_min, HitInfo<F> &best)
+{
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    if (idx < msph_base) {
+        const SphereHot<F> g = hot[idx];
+        sphere_unordered<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, idx, tri_base, best);
+    }
+    else if (idx < tri_base) {
+        const MovingSphereRec<F> ms = P.msph[idx - msph_base];
+        const V3<F> cen = msphere_center<F>(ms, path.tm);
+        sphere_unordered<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, idx, tri_base, best);
+    }
+    else {
+        F tt;
+        if (triangle_test<F, true>(P.tri[idx - tri_base], path, t_min, Limits<F>::inf(), tt)) consider<F>(tt, idx, tri_base, best);
+    }
+}
+template <typename F, typename PP, typename HotTab, typename CellTab, typename PrimTab>
+RRTX_DEV bool accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best)
+{
+    const F ox = path.o.x, oy = path.o.y, oz = path.o.z, dx = path.d.x, dy = path.d.y, dz = path.d.z;
+    F dist2;
+    {
+        // the rays the unordered rule is proven for
+        const F o2 = ox * ox + oy * oy + oz * oz;
+        const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
+        dist2 = rx * rx + ry * ry + rz * rz;
+        const bool ok = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
+        if (!ok) return false;
+    }
+    for (int i = 0; i < P.n_always; ++i) test_primitive<F>(P, hot, (int)P.grid_always[i], path, a, t_min, best);
+
+    // Rays that start beyond `far`: their exact test can "hit" spheres the line misses by more than
+    // the cells' inflation — but by less than sqrt(m), m = 32 eps (|o - c|^2 + r^2).  Almost
+    // all of them (the bounce off the distant ground, up into the sky) miss the grid's box even when it
+    // is blown up by that much: no gridded primitive can answer them.  The few that do not are scanned.
+    const bool is_far = dist2 > P.grid.far2;
+    const F reach = P.grid.slack1 * (fsqrt(dist2) + P.grid.half_diag); // 1.5 sqrt(32 eps) (|o - centre| + half diagonal)
+    const F fat = is_far ? reach + reach : (F)0;
+
+    // clip the ray to the grid's box: [t_in, t_out]
+    F t_in = 0, t_out = Limits<F>::inf();
+    F inv[3], tmax[3];
+    int ci[3];
+    bool miss = false;
+    const F o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const F glo = P.grid.gmin[k] - fat, ghi = P.grid.gmax[k] + fat;
+        if (d[k] != 0) {
+            inv[k] = (F)1 / d[k];
+            const F t1 = (glo - o[k]) * inv[k], t2 = (ghi - o[k]) * inv[k];
+            const F lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+            t_in = lo > t_in ? lo : t_in;
+            t_out = hi < t_out ? hi : t_out;
+        }
+        else {
+            inv[k] = Limits<F>::inf();
+            if (o[k] < glo || o[k] > ghi) miss = true;
+        }
+    }
+    if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return true; // (a hair of tolerance on the far side: the slab arithmetic rounds too)
+    if (is_far) return false;
+    const F inv_len = (F)1 / fsqrt(a);
+    const F slack_t = (P.grid.slack + reach) * inv_len;
+    if (t_in > best.t + slack_t) return true;
+    // the cell of the entry point, and the DDA's per-axis distances to the next cell boundary
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const F pk = o[k] + d[k] * t_in;
+        int c = (int)((pk - P.grid.gmin[k]) * P.grid.inv_cell[k]);
+        c = c < 0 ? 0 : (c > P.grid.dims[k] - 1 ? P.grid.dims[k] - 1 : c);
+        ci[k] = c;
+        if (d[k] != 0) {
+            const F boundary = P.grid.gmin[k] + (F)(c + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k];
+            tmax[k] = (boundary - o[k]) * inv[k];
+        }
+        else
+            tmax[k] = Limits<F>::inf();
+    }
+    for (int step = 0; step < P.grid.max_steps; ++step) {
+        const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
+        const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
+        for (uint32_t k = beg; k < end; ++k) test_primitive<F>(P, hot, (int)cell_prims[k], path, a, t_min, best);
+        // next cell: across the nearest boundary
+        const int axis = tmax[0] <= tmax[1] ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+        const F t_next = axis == 0 ? tmax[0] : (axis == 1 ? tmax[1] : tmax[2]);
+        if (t_next > t_out || t_next > best.t + slack_t) break;
+        // (written out per axis: dynamic indexing of the small arrays would put them in scratch)
+        if (axis == 0) {
+            ci[0] += dx > 0 ? 1 : -1;
+            if (ci[0] < 0 || ci[0] >= P.grid.dims[0]) break;
+            tmax[0] += P.grid.cell[0] * ffabs(inv[0]);
+        }
+        else if (axis == 1) {
+            ci[1] += dy > 0 ? 1 : -1;
+            if (ci[1] < 0 || ci[1] >= P.grid.dims[1]) break;
+            tmax[1] += P.grid.cell[1] * ffabs(inv[1]);
+        }
+        else {
+            ci[2] += dz > 0 ? 1 : -1;
+            if (ci[2] < 0 || ci[2] >= P.grid.dims[2]) break;
+            tmax[2] += P.grid.cell[2] * ffabs(inv[2]);
+        }
+    }
+    return true;
+}
+
 // Per-segment half of the conservative scan filter (see the render kernel's phase 1 and DESIGN.md
 // "Conservative scan filter"): with n = d/|d|, u = c.n, s = o.n,
 //   disc/|d|^2 = u^2 + 2(o - s n).c + (s^2 - |o|^2) + (r^2 - |c|^2);
@@ -516,14 +663,28 @@ template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy,
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
+// ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
+// and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
+// rays the grid is not proven for.
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
 {
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCandCap][64];
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     SphereHot<F> *const sph_lds = (SphereHot<F> *)dyn_lds;
     if (LDSMODE != 0) {
         const SphereHot<F> *src = FILTER ? P.sph_filter : P.sph_hot;
         for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) sph_lds[i] = src[i];
+        __syncthreads();
+    }
+    static_assert(ACCEL == 0 || LDSMODE == 0, "the accelerated variants scan from scalar loads");
+    // ACCEL == 2: [exact-test records][cell_start][cell_prims] in LDS
+    SphereHot<F> *const hot_lds = (SphereHot<F> *)dyn_lds;
+    uint32_t *const cell_start_lds = (uint32_t *)(hot_lds + P.n_sph_padded);
+    uint16_t *const cell_prims_lds = (uint16_t *)(cell_start_lds + P.n_grid_cells + 1);
+    if (ACCEL == 2) {
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) hot_lds[i] = P.sph_hot[i];
+        for (int i = threadIdx.x; i <= P.n_grid_cells; i += kBlockThreads) cell_start_lds[i] = P.grid_cell_start[i];
+        for (int i = threadIdx.x; i < P.n_grid_prims; i += kBlockThreads) cell_prims_lds[i] = P.grid_cell_prims[i];
         __syncthreads();
     }
 
@@ -792,6 +953,37 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 }
             }
             else {
+            bool need_scan = true;
+            if (ACCEL != 0) {
+                const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
+                if (ACCEL == 2)
+                    need_scan = !accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best);
+                else
+                    need_scan = !accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best);
+                if (VERIFY && !need_scan) { // test build of the kernel: the walk must reproduce the full sequential scan
+                    HitInfo<F> full;
+                    full.t = Limits<F>::inf();
+                    full.idx = -1;
+                    for (int q = 0; q < n_sph; ++q) {
+                        const SphereHot<F> gq = P.sph_hot[q];
+                        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
+                    }
+                    for (int q = 0; q < n_msph; ++q) {
+                        const MovingSphereRec<F> ms = P.msph[q];
+                        const V3<F> cen = msphere_center<F>(ms, path.tm);
+                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
+                    }
+                    for (int q = 0; q < n_tri; ++q) {
+                        F tt;
+                        if (triangle_test<F, true>(P.tri[q], path, t_min, full.t, tt)) {
+                            full.t = tt;
+                            full.idx = tri_base + q;
+                        }
+                    }
+                    if (full.idx != best.idx || !(full.t == best.t)) atomicAdd(&P.counters[2], 1ull);
+                }
+            }
+            if (need_scan) {
             n_scanned += 1;
             uint32_t cnt = 0;
 
@@ -923,6 +1115,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY> __global__ void __l
                 }
             }
             drain();
+            } // need_scan
             } // scan pass
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
@@ -1338,20 +1531,32 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
+}
+// bytes of LDS the accelerated variant wants for its tables (0: they stay in HBM)
+template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
+{
+    const size_t b = (size_t)P.n_sph_padded * sizeof(SphereHot<F>) + ((size_t)P.n_grid_cells + 1) * 4 + (((size_t)P.n_grid_prims * 2 + 15) & ~(size_t)15);
+    return b <= (size_t)kLdsSceneBytes ? b : 0;
 }
 template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)
 {
     const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
-    if (P.verify_lists) return launch_variant<F, true, 0, true>(P, grid_blocks, 0, stream); // test build: filter + scalar loads + list check
-    if (!filter) return launch_variant<F, false, 0, false>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
+    if (P.grid_cell_start) { // accelerated closest hit; the scan (scalar loads) is its fallback
+        const size_t alds = accel_lds_bytes<F>(P);
+        if (P.verify_lists) return launch_variant<F, true, 0, true, 1>(P, grid_blocks, 0, stream);
+        if (!filter) return alds ? launch_variant<F, false, 0, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, false, 0, false, 1>(P, grid_blocks, 0, stream);
+        return alds ? launch_variant<F, true, 0, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, true, 0, false, 1>(P, grid_blocks, 0, stream);
+    }
+    if (P.verify_lists) return launch_variant<F, true, 0, true, 0>(P, grid_blocks, 0, stream); // test build: filter + scalar loads + list check
+    if (!filter) return launch_variant<F, false, 0, false, 0>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
     switch (lds_mode) {
-    case 1: return launch_variant<F, true, 1, false>(P, grid_blocks, lds, stream);
-    case 2: return launch_variant<F, true, 2, false>(P, grid_blocks, lds, stream);
-    default: return launch_variant<F, true, 0, false>(P, grid_blocks, 0, stream);
+    case 1: return launch_variant<F, true, 1, false, 0>(P, grid_blocks, lds, stream);
+    case 2: return launch_variant<F, true, 2, false, 0>(P, grid_blocks, lds, stream);
+    default: return launch_variant<F, true, 0, false, 0>(P, grid_blocks, 0, stream);
     }
 }
 template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, uint16_t *plist, hipStream_t stream)
@@ -1391,14 +1596,22 @@ template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const 
     hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, S);
     return hipGetLastError();
 }
-template <typename F> hipError_t render_occupancy(bool filter, int lds_mode, int n_sph_padded, int *blocks_per_cu)
+template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool filter, int lds_mode, int *blocks_per_cu)
 {
-    const size_t lds = lds_mode ? (size_t)n_sph_padded * sizeof(SphereHot<F>) : 0;
-    if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false>, kBlockThreads, 0);
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
+    if (P.grid_cell_start) {
+        const size_t alds = accel_lds_bytes<F>(P);
+        if (!filter)
+            return alds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 2>, kBlockThreads, alds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 1>, kBlockThreads, 0);
+        return alds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 2>, kBlockThreads, alds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 1>, kBlockThreads, 0);
+    }
+    if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 0>, kBlockThreads, 0);
     switch (lds_mode) {
-    case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false>, kBlockThreads, lds);
-    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false>, kBlockThreads, lds);
-    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false>, kBlockThreads, 0);
+    case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false, 0>, kBlockThreads, lds);
+    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false, 0>, kBlockThreads, lds);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 0>, kBlockThreads, 0);
     }
 }
 
@@ -1410,7 +1623,7 @@ template hipError_t launch_tail<float>(const KernelParams<float> &, bool, int, h
 template hipError_t launch_tail<double>(const KernelParams<double> &, bool, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, const FinalizeShape &, hipStream_t);
 template hipError_t launch_finalize<double>(const double *, double *, const FinalizeShape &, hipStream_t);
-template hipError_t render_occupancy<float>(bool, int, int, int *);
-template hipError_t render_occupancy<double>(bool, int, int, int *);
+template hipError_t render_occupancy<float>(const KernelParams<float> &, bool, int, int *);
+template hipError_t render_occupancy<double>(const KernelParams<double> &, bool, int, int *);
 
 } // namespace rrtx
