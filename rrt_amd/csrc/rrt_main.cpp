@@ -41,7 +41,7 @@ static void usage(const char *arg)
     std::cerr << "  -h <height>         : output image height. (800)\n";
     std::cerr << "  -s <samples>        : number of samples per pixel. (10)\n";
     std::cerr << "  -d <max_depth>      : may ray recursion depth. (50)\n";
-    std::cerr << "  -b                  : disable bvh acceleration (accepted; this build always scans the list).\n";
+    std::cerr << "  -b                  : disable acceleration (scan the primitive list for every ray segment).\n";
     std::cerr << "  -tx <num_threads_x> : number of threads per block in x. (8)\n";
     std::cerr << "  -ty <num_threads_y> : number of threads per block in y. (8)\n";
     std::cerr << "  -q                  : query devices & HIP info\n";
@@ -172,9 +172,7 @@ int main(int argc, char *argv[])
     std::cerr << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
     rrtx_stats st;
     std::memset(&st, 0, sizeof st);
-    std::cerr << "(" << kFpName << ", brute-force list scan";
-    if (prm.use_bvh) std::cerr << "; BVH not used by this build";
-    std::cerr << ").\n";
+    std::cerr << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
     std::cerr << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
     std::cerr << "HIP Device: " << prm.device << std::endl;
 
@@ -193,7 +191,7 @@ int main(int argc, char *argv[])
               << prm.samples_per_pixel << "," << st.grid_blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
     if (seconds > 0)
         std::cerr << "rate," << (double)st.samples / seconds / 1e6 << " Msamples/s," << st.segments << " segments," << st.prim_tests << " primitive tests,"
-                  << (double)st.bytes_algorithmic / seconds / 1e9 << " GB/s algorithmic\n";
+                  << (double)st.bytes_algorithmic / seconds / 1e9 << " GB/s algorithmic," << (st.accel_cells ? "grid of " + std::to_string(st.accel_cells) + " cells" : std::string("list scan")) << "\n";
 
     std::vector<uint8_t> rgb((size_t)prm.image_width * prm.image_height * 3);
     rrtx_quantise(fb.data(), kFp64, prm.image_width, prm.image_height, prm.samples_per_pixel, rgb.data());

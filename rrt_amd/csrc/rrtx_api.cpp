@@ -137,10 +137,11 @@ template <typename F> void pack_unit(const F v[3], F out[3])
 // ---------------------------------------------------------------------------------------------
 // Acceleration grid for use_bvh != 0 (device side: accel_closest_hit).
 //
-// Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2.5 x their median
-// extent); primitives larger than 1.6 cells, spheres smaller than a fiftieth of a cell and all
-// triangles go into the "always" list.  Every gridded primitive is entered into all cells its box,
-// inflated by delta = 0.1 cell, overlaps.  Why that is enough: the reference's discriminant,
+// Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2 x their median
+// extent; measured on final.txt: 1.5 / 2 / 2.5 / 3.5 -> 53.2 / 49.5 / 51.5 / 74 ms at spp 504); primitives
+// larger than 1.6 cells, spheres smaller than a fiftieth of a cell and all triangles go into the
+// "always" list.  Every gridded primitive is entered into all cells its box, inflated by
+// delta = 0.05 cell (0.03 / 0.05 / 0.1 / 0.2 -> 50.2 / 50.8 / 51.5 / 62 ms), overlaps.  Why that is enough: the reference's discriminant,
 // evaluated in floating point, can be >= 0 only if the ray's line passes within
 // sqrt(r^2 + m) of the centre, m = 32 eps (|o - c|^2 + r^2) (a bound on the rounding error of
 // (oc.d)^2 - |d|^2 (|oc|^2 - r^2) relative to |d|^2; 24 eps by the usual gamma_n accounting), and the
@@ -193,7 +194,7 @@ static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const 
     for (const Box &b : boxes) ext.push_back(std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}));
     std::vector<double> sorted = ext;
     std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-    double cell = 2.5 * sorted[sorted.size() / 2];
+    double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
     if (!(cell > 0) || !std::isfinite(cell)) return false;
 
     for (int attempt = 0; attempt < 8; ++attempt, cell *= 1.6) {
@@ -209,7 +210,7 @@ static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const 
         for (int i = 0; i < n_tri; ++i) always.push_back((uint32_t)(tri_base + i));
         if (always.size() > 48) continue; // a larger cell turns "large" primitives into ordinary ones
         if (gridded.size() < 32) return false;
-        const double delta = 0.1 * cell;
+        const double delta = (getenv("RRTX_GRID_DELTA") ? atof(getenv("RRTX_GRID_DELTA")) : 0.05) * cell;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (int i : gridded)
             for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k] - delta), hi[k] = std::max(hi[k], boxes[i].hi[k] + delta);
@@ -228,7 +229,7 @@ static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const 
         double far = (R2 > 0 ? std::sqrt(R2) : 0) - hd;
         const double far_cap = sizeof(F) == 4 ? 1e6 : 1e50;
         if (far > far_cap) far = far_cap;
-        if (far < 2 * hd) continue; // the grid would not even serve rays that start next to it
+        if (far < 1.5 * hd) continue; // the grid would not even serve rays that start next to it
         // fill
         const int ncell = dims[0] * dims[1] * dims[2];
         std::vector<uint32_t> count(ncell + 1, 0);
@@ -269,7 +270,7 @@ static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const 
         G.slack = (F)(0.01 * cell);              // slack0
         G.slack1 = (F)(1.5 * std::sqrt(32 * eps)); // times (|o - centre| + half diagonal)
         G.half_diag = (F)hd;
-        G.max_steps = dims[0] + dims[1] + dims[2] + 3;
+        G.max_steps = dims[0] + dims[1] + dims[2] + 3 + (int)cell_prims.size(); // trips of the walk: a cell step or a primitive test each
         if (getenv("RRTX_DEBUG_GRID"))
             fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, delta %g, rmin %g rmax %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],
                     cell_prims.size(), always.size(), delta, rmin, rmax, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2]);

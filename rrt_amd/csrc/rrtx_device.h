@@ -101,7 +101,7 @@ template <typename F> struct GridRec {
     F far2;              // rays starting further than sqrt(far2) from `center` take the list scan (their
                          // exact tests are too inaccurate for the inflation the cells were built with)
     F slack, slack1, half_diag; // the walk continues slack + slack1 (|o - center| + half_diag) world units beyond the closest hit so far
-    int32_t max_steps;   // dims[0] + dims[1] + dims[2] + 3
+    int32_t max_steps;   // bound on the trips of the walk (cells stepped through + primitives tested)
 };
 
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,

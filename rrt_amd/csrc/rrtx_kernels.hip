@@ -505,33 +505,51 @@ template <typename F> RRTX_DEV void consider(F t, int idx, int tri_base, HitInfo
         best.idx = idx;
     }
 }
-template <typename F> RRTX_DEV void sphere_unordered(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, int tri_base, HitInfo<F> &best)
+// A sphere whose discriminant is >= 0, waiting for its roots: the square root and the division (~50
+// instructions) are kept out of the loops over primitives, where any one lane taking them costs the
+// whole wave — a lane holds at most one such candidate and resolves it at the end of a cell (or
+// when the next one turns up).
+template <typename F> struct PendingRoot {
+    int idx; // -1: none
+    F half_b, disc;
+};
+template <typename F> RRTX_DEV void resolve_pending(PendingRoot<F> &pend, F a, F t_min, int tri_base, HitInfo<F> &best)
 {
-    // sphere.h:33-49 without the dependence on the scan order (see above)
+    if (pend.idx < 0) return;
+    // sphere.h:41-49 without the dependence on the scan order (see above)
+    const F sq = fsqrt(pend.disc);
+    F root = (-pend.half_b - sq) / a;
+    bool ok = true;
+    if (root < t_min) {
+        root = (-pend.half_b + sq) / a;
+        ok = !(root < t_min);
+    }
+    if (ok) consider<F>(root, pend.idx, tri_base, best);
+    pend.idx = -1;
+}
+template <typename F> RRTX_DEV void sphere_unordered(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, int tri_base, HitInfo<F> &best, PendingRoot<F> &pend)
+{
+    // sphere.h:33-40
     const F ocx = p.o.x - cx, ocy = p.o.y - cy, ocz = p.o.z - cz;
     const F half_b = ocx * p.d.x + ocy * p.d.y + ocz * p.d.z;
     const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
     const F disc = half_b * half_b - a * c;
     if (disc < 0) return;
-    const F sq = fsqrt(disc);
-    F root = (-half_b - sq) / a;
-    if (root < t_min) {
-        root = (-half_b + sq) / a;
-        if (root < t_min) return;
-    }
-    consider<F>(root, idx, tri_base, best);
+    resolve_pending<F>(pend, a, t_min, tri_base, best); // (rare: two candidates in one cell)
+    pend.idx = idx, pend.half_b = half_b, pend.disc = disc;
 }
-template <typename F, typename PP, typename HotTab> RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path<F> &path, F a, F t_min, HitInfo<F> &best)
+template <typename F, typename PP, typename HotTab>
+RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path<F> &path, F a, F t_min, HitInfo<F> &best, PendingRoot<F> &pend)
 {
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
     if (idx < msph_base) {
         const SphereHot<F> g = hot[idx];
-        sphere_unordered<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, idx, tri_base, best);
+        sphere_unordered<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, idx, tri_base, best, pend);
     }
     else if (idx < tri_base) {
         const MovingSphereRec<F> ms = P.msph[idx - msph_base];
         const V3<F> cen = msphere_center<F>(ms, path.tm);
-        sphere_unordered<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, idx, tri_base, best);
+        sphere_unordered<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, idx, tri_base, best, pend);
     }
     else {
         F tt;
@@ -551,7 +569,10 @@ RRTX_DEV bool accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &c
         const bool ok = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
         if (!ok) return false;
     }
-    for (int i = 0; i < P.n_always; ++i) test_primitive<F>(P, hot, (int)P.grid_always[i], path, a, t_min, best);
+    const int tri_base_ = P.n_sph_padded + P.n_msph;
+    PendingRoot<F> pend = {-1, 0, 0};
+    for (int i = 0; i < P.n_always; ++i) test_primitive<F>(P, hot, (int)P.grid_always[i], path, a, t_min, best, pend);
+    resolve_pending<F>(pend, a, t_min, tri_base_, best);
 
     // Rays that start beyond `far`: their exact test can "hit" spheres the line misses by more than
     // the cells' inflation — but by less than sqrt(m), m = 32 eps (|o - c|^2 + r^2).  Almost
@@ -601,30 +622,23 @@ RRTX_DEV bool accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &c
         else
             tmax[k] = Limits<F>::inf();
     }
+    const F dtx = P.grid.cell[0] * ffabs(inv[0]), dty = P.grid.cell[1] * ffabs(inv[1]), dtz = P.grid.cell[2] * ffabs(inv[2]);
+    const int sx = dx > 0 ? 1 : -1, sy = dy > 0 ? 1 : -1, sz = dz > 0 ? 1 : -1;
+    // (a single loop whose trips either test a primitive or step a cell was tried: 59.9 vs 52.6 ms)
     for (int step = 0; step < P.grid.max_steps; ++step) {
         const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
         const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
-        for (uint32_t k = beg; k < end; ++k) test_primitive<F>(P, hot, (int)cell_prims[k], path, a, t_min, best);
-        // next cell: across the nearest boundary
-        const int axis = tmax[0] <= tmax[1] ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
-        const F t_next = axis == 0 ? tmax[0] : (axis == 1 ? tmax[1] : tmax[2]);
+        for (uint32_t k = beg; k < end; ++k) test_primitive<F>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
+        resolve_pending<F>(pend, a, t_min, tri_base_, best);
+        // next cell: across the nearest boundary (branch-free: the three axes diverge otherwise)
+        const bool ax = tmax[0] <= tmax[1] && tmax[0] <= tmax[2];
+        const bool ay = !ax && tmax[1] <= tmax[2];
+        const bool az = !ax && !ay;
+        const F t_next = ax ? tmax[0] : (ay ? tmax[1] : tmax[2]);
         if (t_next > t_out || t_next > best.t + slack_t) break;
-        // (written out per axis: dynamic indexing of the small arrays would put them in scratch)
-        if (axis == 0) {
-            ci[0] += dx > 0 ? 1 : -1;
-            if (ci[0] < 0 || ci[0] >= P.grid.dims[0]) break;
-            tmax[0] += P.grid.cell[0] * ffabs(inv[0]);
-        }
-        else if (axis == 1) {
-            ci[1] += dy > 0 ? 1 : -1;
-            if (ci[1] < 0 || ci[1] >= P.grid.dims[1]) break;
-            tmax[1] += P.grid.cell[1] * ffabs(inv[1]);
-        }
-        else {
-            ci[2] += dz > 0 ? 1 : -1;
-            if (ci[2] < 0 || ci[2] >= P.grid.dims[2]) break;
-            tmax[2] += P.grid.cell[2] * ffabs(inv[2]);
-        }
+        ci[0] += ax ? sx : 0, ci[1] += ay ? sy : 0, ci[2] += az ? sz : 0;
+        tmax[0] += ax ? dtx : (F)0, tmax[1] += ay ? dty : (F)0, tmax[2] += az ? dtz : (F)0;
+        if ((uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2]) break;
     }
     return true;
 }
@@ -960,6 +974,19 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                     need_scan = !accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best);
                 else
                     need_scan = !accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best);
+#ifdef RRTX_EXP_WALK_TWICE // experiment: the cost of the walk = the time this adds
+                {
+                    HitInfo<F> again;
+                    again.t = Limits<F>::inf(), again.idx = -1;
+                    Path<F> p2 = path;
+                    p2.o.x += (F)1e-30f * (F)best.idx; // (defeats common-subexpression elimination; changes nothing)
+                    if (ACCEL == 2)
+                        accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, p2, a, t_min, again);
+                    else
+                        accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, p2, a, t_min, again);
+                    if (again.idx == -12345) best.t = again.t;
+                }
+#endif
                 if (VERIFY && !need_scan) { // test build of the kernel: the walk must reproduce the full sequential scan
                     HitInfo<F> full;
                     full.t = Limits<F>::inf();

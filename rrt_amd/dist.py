@@ -71,7 +71,7 @@ class ShardedRenderer:
     """Rrt bound to this rank's shard, rendering into a torch CUDA tensor (no host round trip)."""
 
     def __init__(self, scene_file, image_width, image_height, samples_per_pixel, max_depth=50, *, fp64=False, tile_rows=4, sample_chunk=0, seed=1984, group=None,
-                 device=None, collect_stats=True):
+                 device=None, collect_stats=True, use_bvh=False):
         from .render import Rrt, Scene
 
         self.group = group
@@ -81,7 +81,7 @@ class ShardedRenderer:
         self.h, self.w, self.spp = image_height, image_width, samples_per_pixel
         self.tile_rows = tile_rows
         self.scene = Scene(scene_file, image_width, image_height, fp64=fp64)
-        self.rrt = Rrt(image_width, image_height, samples_per_pixel, max_depth, use_bvh=False, fp64=fp64, device=self.device.index or 0, seed=seed, sample_chunk=sample_chunk,
+        self.rrt = Rrt(image_width, image_height, samples_per_pixel, max_depth, use_bvh=use_bvh, fp64=fp64, device=self.device.index or 0, seed=seed, sample_chunk=sample_chunk,
                        shard_rank=self.rank, shard_count=self.world, tile_rows=tile_rows, collect_stats=collect_stats)
         self.rrt.set_scene(self.scene)
         self.rows = self.rrt.shard_rows()

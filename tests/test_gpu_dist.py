@@ -8,6 +8,13 @@ from _oracle import Oracle, scene_path
 pytestmark = pytest.mark.gpu
 
 
+def _list_rrt(gpu, *args, **kw):
+    """Rrt on the list scan (`-b`): what most tests here exercise.  The accelerated closest hit (use_bvh,
+    the CLI's default) has its own tests; its images must equal these bit for bit."""
+    kw.setdefault("use_bvh", False)
+    return gpu.Rrt(*args, **kw)
+
+
 def test_render_into_a_torch_tensor_on_the_current_stream(gpu):
     import torch
 
@@ -88,7 +95,7 @@ def test_sharded_render_across_ranks_equals_the_full_frame(gpu, tmp_path, world,
     s.close()
     mp.spawn(_rank_main, args=(world, port, str(tmp_path), w, h, spp, tile_rows), nprocs=world, join=True)
     got = np.load(tmp_path / "frame.npy")
-    r = gpu.Rrt(w, h, spp, 50)
+    r = _list_rrt(gpu, w, h, spp, 50)
     want = r.render(gpu.Scene(scene_path("final"), w, h))
     r.close()
     assert np.array_equal(got, want)

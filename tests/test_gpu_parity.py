@@ -17,12 +17,19 @@ from _oracle import GOLDEN, ROOT, Oracle, scene_path
 
 pytestmark = pytest.mark.gpu
 
+
+def _list_rrt(gpu, *args, **kw):
+    """Rrt on the list scan (`-b`): what most tests here exercise.  The accelerated closest hit (use_bvh,
+    the CLI's default) has its own tests; its images must equal these bit for bit."""
+    kw.setdefault("use_bvh", False)
+    return gpu.Rrt(*args, **kw)
+
 SCENES = {"test1": scene_path("test1"), "test2": scene_path("test2"), "test3": scene_path("test3"), "final": scene_path("final"), "xform": os.path.join(GOLDEN, "scenes", "xform.txt")}
 
 
 def _render(gpu, path, w, h, spp, depth=50, fp64=False, **kw):
     sc = gpu.Scene(path, w, h, fp64=fp64)
-    r = gpu.Rrt(w, h, spp, depth, use_bvh=False, fp64=fp64, **kw)
+    r = gpu.Rrt(w, h, spp, depth, use_bvh=kw.pop("use_bvh", False), fp64=fp64, **kw)
     fb = r.render(sc)
     st = r.stats
     r.close()
@@ -92,7 +99,7 @@ def test_seeds_change_the_image_and_are_reproducible(gpu):
 
 def test_scene_swap_on_a_live_context(gpu):
     w, h, spp = 40, 24, 2
-    r = gpu.Rrt(w, h, spp, 50, sample_chunk=-1)
+    r = _list_rrt(gpu, w, h, spp, 50, sample_chunk=-1)
     for name in ("final", "test3", "test2", "final"):
         fb = r.render(gpu.Scene(SCENES[name], w, h))
         assert np.array_equal(fb, Oracle(SCENES[name], w, h, False).render(spp, 50, 1984, order=1)[0]), name
@@ -104,7 +111,7 @@ def test_scene_from_reference_layout_tables(gpu):
     w, h, spp = 32, 20, 2
     t = gpu.Scene(SCENES["xform"], w, h).tables()
     sc = gpu.Scene.from_tables(t["camera"], t["materials"], t["spheres"], t["moving_spheres"], t["triangles"])
-    r = gpu.Rrt(w, h, spp, 50, sample_chunk=-1)
+    r = _list_rrt(gpu, w, h, spp, 50, sample_chunk=-1)
     fb = r.render(sc)
     r.close()
     assert np.array_equal(fb, Oracle(SCENES["xform"], w, h, False).render(spp, 50, 1984, order=1)[0])
@@ -118,7 +125,7 @@ def test_row_tile_shards_assemble_to_the_unsharded_frame(gpu, count, tile):
     acc = np.zeros_like(full)
     seen = np.zeros(h, dtype=int)
     for rank in range(count):
-        r = gpu.Rrt(w, h, spp, 50, shard_rank=rank, shard_count=count, tile_rows=tile)
+        r = _list_rrt(gpu, w, h, spp, 50, shard_rank=rank, shard_count=count, tile_rows=tile)
         part = r.render(sc)
         rows = r.shard_rows()
         assert np.array_equal(rows, np.arange(h)[(np.arange(h) // tile) % count == rank])
@@ -131,7 +138,7 @@ def test_row_tile_shards_assemble_to_the_unsharded_frame(gpu, count, tile):
 
 
 def test_invalid_scenes_and_arguments_fail_loudly(gpu):
-    r = gpu.Rrt(16, 16, 1, 5)
+    r = _list_rrt(gpu, 16, 16, 1, 5)
     with pytest.raises(gpu.RrtxError) as e:
         r.render()  # no scene
     assert e.value.code == -3
@@ -144,7 +151,7 @@ def test_invalid_scenes_and_arguments_fail_loudly(gpu):
         r.render(gpu.Scene.from_tables(t["camera"], t["materials"], t["spheres"]))
     r.close()
     with pytest.raises(gpu.RrtxError):
-        gpu.Rrt(16, 16, 1, 5, device=1000)
+        _list_rrt(gpu, 16, 16, 1, 5, device=1000)
 
 
 def test_many_candidates_force_list_flushes(gpu, tmp_path):
@@ -226,7 +233,7 @@ def test_config3_final_1200x800_rows_and_shard_invariance(gpu):
     sc = gpu.Scene(SCENES["final"], w, h)
     acc = np.zeros_like(full)
     for rank in range(8):  # the 8-GPU decomposition, executed on one device
-        r = gpu.Rrt(w, h, spp, 50, shard_rank=rank, shard_count=8, tile_rows=4)
+        r = _list_rrt(gpu, w, h, spp, 50, shard_rank=rank, shard_count=8, tile_rows=4)
         part = r.render(sc)
         rows = r.shard_rows()
         acc[rows] = part[rows]
@@ -279,7 +286,7 @@ def test_scan_variants_are_bit_identical(gpu, fp64):
     want, so = o.render(spp, 50, 1984, order=1)
     sc = gpu.Scene(SCENES["final"], w, h, fp64=fp64)
     for flags in (1, 2, 0, 4, 8, 1 | 8, 4 | 8):
-        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=-1, flags=flags)
+        r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, sample_chunk=-1, flags=flags)
         fb = r.render(sc)
         assert np.array_equal(fb, want), "flags=%d" % flags
         assert r.stats["segments"] == so["segments"]
@@ -292,7 +299,7 @@ def test_hand_off_thresholds_do_not_change_the_image(gpu):
     want, _ = Oracle(SCENES["final"], w, h, False).render(spp, 50, 1984, order=1, chunk=8)
     sc = gpu.Scene(SCENES["final"], w, h)
     for lanes, iters in ((1, 1), (7, 8), (64, 1), (32, 1000)):
-        r = gpu.Rrt(w, h, spp, 50, handoff_lanes=lanes, handoff_iters=iters)
+        r = _list_rrt(gpu, w, h, spp, 50, handoff_lanes=lanes, handoff_iters=iters)
         assert np.array_equal(r.render(sc), want), (lanes, iters)
         r.close()
 
@@ -306,14 +313,14 @@ def test_single_sample_taper_does_not_change_the_image(gpu, fp64):
     for chunk in (8, 5, -1):
         want, _ = Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp if chunk < 0 else chunk)
         for taper in (-1, 1, spp * w * 3 + 7, w * h * spp // 2, 2**31 - 1):
-            r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=chunk, taper_samples=taper)
+            r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, sample_chunk=chunk, taper_samples=taper)
             assert np.array_equal(r.render(sc), want), (chunk, taper)
             r.close()
     # sharded: each shard tapers its own queue
     want, _ = Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
     got = np.zeros_like(want)
     for rank in range(3):
-        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, shard_rank=rank, shard_count=3, tile_rows=4, taper_samples=w * 5 * spp + 3)
+        r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, shard_rank=rank, shard_count=3, tile_rows=4, taper_samples=w * 5 * spp + 3)
         part = r.render(sc)
         rows = r.shard_rows()
         got[rows] = part[rows]
@@ -391,11 +398,11 @@ def test_camera_ray_lists_reproduce_the_scan(gpu, name, fp64):
     rays can hit (defocus blur, shutter time, moving spheres and triangles included)."""
     w, h, spp = 160, 100, 16
     sc = gpu.Scene(SCENES[name], w, h, fp64=fp64)
-    r = gpu.Rrt(w, h, spp, 50, fp64=fp64, flags=32)
+    r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, flags=32)
     a = r.render(sc)
     assert r.stats["list_mismatches"] == 0
     r.close()
-    r = gpu.Rrt(w, h, spp, 50, fp64=fp64, flags=16)  # lists off: every segment through the scan
+    r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, flags=16)  # lists off: every segment through the scan
     b = r.render(sc)
     r.close()
     assert np.array_equal(a, b)
@@ -413,8 +420,72 @@ def test_camera_ray_lists_with_wide_lenses_and_odd_cameras(gpu, tmp_path):
         f = _write_scene(tmp_path / ("cam%d.txt" % k), sph, cam)
         for w, h in ((64, 40), (33, 57)):
             sc = gpu.Scene(f, w, h)
-            r = gpu.Rrt(w, h, 8, 50, flags=32, sample_chunk=-1)
+            r = _list_rrt(gpu, w, h, 8, 50, flags=32, sample_chunk=-1)
             fb = r.render(sc)
             assert r.stats["list_mismatches"] == 0, (cam, w, h)
             r.close()
             assert np.array_equal(fb, Oracle(f, w, h, False).render(8, 50, 1984, order=1)[0]), (cam, w, h)
+
+
+# ---- accelerated closest hit (use_bvh): images must equal the list scan's bit for bit ----
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_accelerated_closest_hit_is_bit_identical(gpu, fp64):
+    """use_bvh resolves segments through a uniform grid + always-list with the exact test and the
+    sequential scan's tie rules; the image equals the oracle's (= the list scan's), and the kernel's
+    test build finds no segment whose grid walk disagrees with the full sequential scan."""
+    w, h, spp = 240, 160, 12
+    want, stats = Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True)
+    assert st["accel_cells"] > 0
+    assert st["segments"] == stats["segments"]
+    assert st["scanned_segments"] < st["segments"] // 100  # the list scan is only the fallback
+    assert np.array_equal(fb, want)
+    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, flags=32)
+    assert np.array_equal(fb, want)
+    assert st["list_mismatches"] == 0
+    # sharded and with whole-pixel tasks
+    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, sample_chunk=-1)
+    assert np.array_equal(fb, Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)[0])
+
+
+def test_small_scenes_keep_the_list_scan(gpu):
+    for name in ("test1", "test2", "test3", "xform"):
+        fb, st = _render(gpu, SCENES[name], 64, 40, 4, use_bvh=True)
+        assert st["accel_cells"] == 0
+        assert np.array_equal(fb, _render(gpu, SCENES[name], 64, 40, 4)[0])
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_accelerated_closest_hit_on_hostile_geometry(gpu, tmp_path, fp64):
+    """Grid cells against everything that could fool them: coincident and nested spheres (exact ties:
+    the LAST one must win), spheres touching cell boundaries, tiny and huge ones (always-list), moving
+    spheres, triangles, rays that start inside spheres (glass), a far-away camera (rays beyond the grid's
+    proven range take the scan), and a wide lens."""
+    rng = np.random.default_rng(5)
+    lines = ["material a lambertian 0.7 0.4 0.3", "material g dielectric 1.5", "material m metal 0.8 0.8 0.9 0.1", "material n metal 0.9 0.6 0.2 0.0"]
+    mats = ["a", "g", "m", "n"]
+    sph = [(0.0, -500.0, 0.0, 500.0, "a")]
+    for i in range(12):
+        for j in range(12):
+            x, z = i - 6.0, j - 6.0  # exactly on the cell lattice for a cell of 1
+            sph.append((x, 0.25, z, 0.25, mats[(i + j) % 4]))
+    sph += [(0.5, 0.25, 0.5, 0.25, "g"), (0.5, 0.25, 0.5, 0.25, "m")]          # coincident: equal roots, the later index wins
+    sph += [(1.5, 0.3, 1.5, 0.3, "g"), (1.5, 0.3, 1.5, 0.2, "a")]                # nested in glass
+    sph += [(-2.5, 0.004, 2.5, 0.004, "m"), (2.5, 3.0, -2.5, 3.0, "n")]          # tiny and large: always-list
+    sph += [(float(x), 0.2, float(z), 0.2, mats[k % 4]) for k, (x, z) in enumerate(rng.uniform(-6, 6, (40, 2)))]
+    lines += ["sphere %r %r %r %r %s" % s for s in sph]
+    for k in range(40):
+        x, z = rng.uniform(-6, 6, 2)
+        lines.append("msphere %r 0.2 %r %r 0.5 %r 0.0 1.0 0.2 %s" % (float(x), float(z), float(x + 0.3), float(z - 0.2), mats[k % 4]))
+    lines += ["obj_beg 4 2", "obj_vtx -1 0 -1", "obj_vtx 1 0 -1", "obj_vtx 1 0 1", "obj_vtx -1 0 1", "obj_tri 0 2 1", "obj_tri 0 3 2", "obj_end", "obj 0 n t 0 1.2 0 r 30 1 0 0", "obj 0 a t 3 0.9 -3 s 2 1 2"]
+    for cam in ("camera 9 2 7 0 0 0 0 1 0 35 0.1 10 0.0 1.0", "camera 0.5 0.3 0.5 3 0.2 3 0 1 0 70 0.3 2 0.0 1.0", "camera 300 40 200 0 0 0 0 1 0 3 0.0 360 0.0 1.0"):
+        path = tmp_path / "hostile.txt"
+        path.write_text("\n".join([cam] + lines) + "\n")
+        w, h, spp = 96, 64, 6
+        want, _ = Oracle(str(path), w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)
+        fb, st = _render(gpu, str(path), w, h, spp, fp64=fp64, use_bvh=True, flags=32)
+        assert st["accel_cells"] > 0, cam
+        assert st["list_mismatches"] == 0, cam
+        assert np.array_equal(fb, want), cam
+        assert np.array_equal(_render(gpu, str(path), w, h, spp, fp64=fp64, use_bvh=True)[0], want), cam
