@@ -677,12 +677,18 @@ template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy,
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
+#ifndef RRTX_ACCEL_WAVES
+#define RRTX_ACCEL_WAVES 1 // waves per SIMD the accelerated variants are compiled for (register budget)
+#endif
 // ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
 // and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
 // rays the grid is not proven for.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? RRTX_ACCEL_WAVES : 1)) render_kernel(const KernelParams<F> P)
 {
-    __shared__ uint32_t cand_lds[kWavesPerBlock][kCandCap][64];
+    // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
+    // thousand and rather keep the LDS for a sixth block per CU
+    constexpr int kCap = ACCEL != 0 ? 8 : kCandCap;
+    __shared__ uint32_t cand_lds[kWavesPerBlock][kCap][64];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     SphereHot<F> *const sph_lds = (SphereHot<F> *)dyn_lds;
     if (LDSMODE != 0) {
@@ -1059,7 +1065,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             auto scan_block = [&](int k0, auto from_lds_c, auto n_c) {
                 constexpr bool FROM_LDS = decltype(from_lds_c)::value != 0;
                 constexpr int N = decltype(n_c)::value;
-                if (__ballot(cnt > (uint32_t)(kCandCap - N)) != 0ull) drain();
+                if (__ballot(cnt > (uint32_t)(kCap - N)) != 0ull) drain();
                 // the block's records first (s_load_dwordx16s, or N ds_read_b128 broadcasts), then
                 // N x {test, push}
                 F bcx[N], bcy[N], bcz[N], bw[N];
@@ -1120,7 +1126,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             }
             // phase 1b: moving spheres (center depends on the ray's time: per-lane)
             for (int m = 0; m < n_msph; ++m) {
-                if (__ballot(cnt >= (uint32_t)kCandCap) != 0ull) drain();
+                if (__ballot(cnt >= (uint32_t)kCap) != 0ull) drain();
                 const MovingSphereRec<F> ms = P.msph[m];
                 const V3<F> cen = msphere_center<F>(ms, path.tm);
                 const F ocx = path.o.x - cen.x, ocy = path.o.y - cen.y, ocz = path.o.z - cen.z;
@@ -1134,7 +1140,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             }
             // phase 1c: triangles
             for (int t = 0; t < n_tri; ++t) {
-                if (__ballot(cnt >= (uint32_t)kCandCap) != 0ull) drain();
+                if (__ballot(cnt >= (uint32_t)kCap) != 0ull) drain();
                 F dummy;
                 if (triangle_test<F, false>(P.tri[t], path, t_min, best.t, dummy)) {
                     my_cand[cnt * 64] = (uint32_t)(tri_base + t);
