@@ -1,7 +1,7 @@
 """rrt_amd - host-side mirror of the rogerallen/rrt render interface over the MI355X-native C ABI.
 
     scene = rrt_amd.Scene("scenes/final.txt", 1200, 800)          # scene.h:212  scene(filename, w, h)
-    rrt   = rrt_amd.Rrt(1200, 800, 500, 50, use_bvh=False)        # rrt.h:16     Rrt(w, h, spp, depth, bvh[, tx, ty])
+    rrt   = rrt_amd.Rrt(1200, 800, 500, 50, use_bvh=True)         # rrt.h:16     Rrt(w, h, spp, depth, bvh[, tx, ty])
     fb    = rrt.render(scene)                                     # rrt.h:34     vec3* render(scene*)
     rgb   = rrt_amd.quantise(fb, 500)                             # color.h:8    convert_color, main.cpp:153 row flip
     rrt_amd.write_png("out.png", rgb)                             # main.cpp:164

@@ -85,7 +85,8 @@ def test_product_parser_produces_the_reference_bytes(fp64):
 
 @pytest.mark.parametrize("name", ["test1", "test2", "test3", "final"])
 def test_reference_bvh_and_list_scan_agree(name):
-    # the product ignores -b / use_bvh (it always scans the list).  With per-sample RNG streams the
+    # the product's use_bvh mode (its acceleration grid) reproduces the list scan bit for bit, so the list
+    # image is the target in both modes.  How far is the reference's own BVH from that?  With per-sample RNG streams the
     # reference's own BVH build (which draws from the stream before any sample is keyed) cannot perturb
     # the samples, so its BVH image and its list image can differ only where two primitives tie in t.
     r = Reference(SCENES[name], 40, 26, False)
