@@ -221,7 +221,7 @@ static bool build_grid(rrtx_ctx *c, const std::vector<SphereHot<F>> &hot, const 
             if (dims[k] < 1) dims[k] = 1;
             total *= dims[k];
         }
-        if (total > 262144.0) continue;
+        if (total > 262144.0 || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) continue; // (the kernel packs a cell's coordinates into 3 x 10 bits)
         const double hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
         const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
         // sqrt(rmin^2 + m) - rmin <= delta  <=>  m <= delta^2 + 2 delta rmin,  m = 32 eps (R^2 + rmax^2)

@@ -556,76 +556,83 @@ RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path
         if (triangle_test<F, true>(P.tri[idx - tri_base], path, t_min, Limits<F>::inf(), tt)) consider<F>(tt, idx, tri_base, best);
     }
 }
+// Walk state a lane carries from one iteration of the render loop to the next: the walk is done in
+// slices of `max_cells` cells, because a wave otherwise waits for its longest walker — path lengths
+// through the sphere layer are roughly exponential (mean 2.5 cells), and the longest of 64 such
+// walks is ~12 cells: 31 % lane utilisation measured.  Lanes whose walk is over go on to shade and
+// start their next segment while the long walkers continue.
+enum { kWalkDone = 0, kWalkNeedsScan = 1, kWalkGoesOn = 2 };
 template <typename F, typename PP, typename HotTab, typename CellTab, typename PrimTab>
-RRTX_DEV bool accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best)
+RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
+                               uint32_t &walk_cell, F &walk_t_out, int max_cells)
 {
     const F ox = path.o.x, oy = path.o.y, oz = path.o.z, dx = path.d.x, dy = path.d.y, dz = path.d.z;
-    F dist2;
-    {
-        // the rays the unordered rule is proven for
-        const F o2 = ox * ox + oy * oy + oz * oz;
-        const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
-        dist2 = rx * rx + ry * ry + rz * rz;
-        const bool ok = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
-        if (!ok) return false;
-    }
+    const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
+    const F dist2 = rx * rx + ry * ry + rz * rz;
+    const F reach = P.grid.slack1 * (fsqrt(dist2) + P.grid.half_diag); // 1.5 sqrt(32 eps) (|o - centre| + half diagonal)
     const int tri_base_ = P.n_sph_padded + P.n_msph;
     PendingRoot<F> pend = {-1, 0, 0};
-    for (int i = 0; i < P.n_always; ++i) test_primitive<F>(P, hot, (int)P.grid_always[i], path, a, t_min, best, pend);
-    resolve_pending<F>(pend, a, t_min, tri_base_, best);
-
-    // Rays that start beyond `far`: their exact test can "hit" spheres the line misses by more than
-    // the cells' inflation — but by less than sqrt(m), m = 32 eps (|o - c|^2 + r^2).  Almost
-    // all of them (the bounce off the distant ground, up into the sky) miss the grid's box even when it
-    // is blown up by that much: no gridded primitive can answer them.  The few that do not are scanned.
-    const bool is_far = dist2 > P.grid.far2;
-    const F reach = P.grid.slack1 * (fsqrt(dist2) + P.grid.half_diag); // 1.5 sqrt(32 eps) (|o - centre| + half diagonal)
-    const F fat = is_far ? reach + reach : (F)0;
-
-    // clip the ray to the grid's box: [t_in, t_out]
-    F t_in = 0, t_out = Limits<F>::inf();
+    const F o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
     F inv[3], tmax[3];
     int ci[3];
-    bool miss = false;
-    const F o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    F t_out = walk_t_out;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const F glo = P.grid.gmin[k] - fat, ghi = P.grid.gmax[k] + fat;
-        if (d[k] != 0) {
-            inv[k] = (F)1 / d[k];
-            const F t1 = (glo - o[k]) * inv[k], t2 = (ghi - o[k]) * inv[k];
-            const F lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
-            t_in = lo > t_in ? lo : t_in;
-            t_out = hi < t_out ? hi : t_out;
+    for (int k = 0; k < 3; ++k) inv[k] = d[k] != 0 ? (F)1 / d[k] : Limits<F>::inf();
+    if (!resume) {
+        {
+            // the rays the unordered rule is proven for
+            const F o2 = ox * ox + oy * oy + oz * oz;
+            const bool ok = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
+            if (!ok) return kWalkNeedsScan;
         }
-        else {
-            inv[k] = Limits<F>::inf();
-            if (o[k] < glo || o[k] > ghi) miss = true;
+        for (int i = 0; i < P.n_always; ++i) test_primitive<F>(P, hot, (int)P.grid_always[i], path, a, t_min, best, pend);
+        resolve_pending<F>(pend, a, t_min, tri_base_, best);
+
+        // Rays that start beyond `far`: their exact test can "hit" spheres the line misses by more than
+        // the cells' inflation — but by less than sqrt(m), m = 32 eps (|o - c|^2 + r^2).  Almost
+        // all of them (the bounce off the distant ground, up into the sky) miss the grid's box even when it
+        // is blown up by that much: no gridded primitive can answer them.  The few that do not are scanned.
+        const bool is_far = dist2 > P.grid.far2;
+        const F fat = is_far ? reach + reach : (F)0;
+
+        // clip the ray to the grid's box: [t_in, t_out]
+        F t_in = 0;
+        t_out = Limits<F>::inf();
+        bool miss = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const F glo = P.grid.gmin[k] - fat, ghi = P.grid.gmax[k] + fat;
+            if (d[k] != 0) {
+                const F t1 = (glo - o[k]) * inv[k], t2 = (ghi - o[k]) * inv[k];
+                const F lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+                t_in = lo > t_in ? lo : t_in;
+                t_out = hi < t_out ? hi : t_out;
+            }
+            else if (o[k] < glo || o[k] > ghi)
+                miss = true;
+        }
+        if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return kWalkDone; // (a hair of tolerance on the far side: the slab arithmetic rounds too)
+        if (is_far) return kWalkNeedsScan;
+        if (t_in > best.t + (P.grid.slack + reach) / fsqrt(a)) return kWalkDone;
+        // the cell of the entry point
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const F pk = o[k] + d[k] * t_in;
+            int c = (int)((pk - P.grid.gmin[k]) * P.grid.inv_cell[k]);
+            ci[k] = c < 0 ? 0 : (c > P.grid.dims[k] - 1 ? P.grid.dims[k] - 1 : c);
         }
     }
-    if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return true; // (a hair of tolerance on the far side: the slab arithmetic rounds too)
-    if (is_far) return false;
-    const F inv_len = (F)1 / fsqrt(a);
-    const F slack_t = (P.grid.slack + reach) * inv_len;
-    if (t_in > best.t + slack_t) return true;
-    // the cell of the entry point, and the DDA's per-axis distances to the next cell boundary
+    else
+        ci[0] = (int)(walk_cell & 1023u), ci[1] = (int)((walk_cell >> 10) & 1023u), ci[2] = (int)(walk_cell >> 20);
+    const F slack_t = (P.grid.slack + reach) / fsqrt(a);
+    // the DDA's per-axis distances to the next cell boundary (from the cell, not accumulated: a resumed
+    // walk must not depend on where it was interrupted)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const F pk = o[k] + d[k] * t_in;
-        int c = (int)((pk - P.grid.gmin[k]) * P.grid.inv_cell[k]);
-        c = c < 0 ? 0 : (c > P.grid.dims[k] - 1 ? P.grid.dims[k] - 1 : c);
-        ci[k] = c;
-        if (d[k] != 0) {
-            const F boundary = P.grid.gmin[k] + (F)(c + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k];
-            tmax[k] = (boundary - o[k]) * inv[k];
-        }
-        else
-            tmax[k] = Limits<F>::inf();
-    }
+    for (int k = 0; k < 3; ++k) tmax[k] = d[k] != 0 ? (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k] : Limits<F>::inf();
     const F dtx = P.grid.cell[0] * ffabs(inv[0]), dty = P.grid.cell[1] * ffabs(inv[1]), dtz = P.grid.cell[2] * ffabs(inv[2]);
     const int sx = dx > 0 ? 1 : -1, sy = dy > 0 ? 1 : -1, sz = dz > 0 ? 1 : -1;
     // (a single loop whose trips either test a primitive or step a cell was tried: 59.9 vs 52.6 ms)
-    for (int step = 0; step < P.grid.max_steps; ++step) {
+    for (int step = 0; step < max_cells; ++step) {
         const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
         const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
         for (uint32_t k = beg; k < end; ++k) test_primitive<F>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
@@ -635,12 +642,14 @@ RRTX_DEV bool accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &c
         const bool ay = !ax && tmax[1] <= tmax[2];
         const bool az = !ax && !ay;
         const F t_next = ax ? tmax[0] : (ay ? tmax[1] : tmax[2]);
-        if (t_next > t_out || t_next > best.t + slack_t) break;
+        if (t_next > t_out || t_next > best.t + slack_t) return kWalkDone;
         ci[0] += ax ? sx : 0, ci[1] += ay ? sy : 0, ci[2] += az ? sz : 0;
         tmax[0] += ax ? dtx : (F)0, tmax[1] += ay ? dty : (F)0, tmax[2] += az ? dtz : (F)0;
-        if ((uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2]) break;
+        if ((uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2]) return kWalkDone;
     }
-    return true;
+    walk_cell = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
+    walk_t_out = t_out;
+    return kWalkGoesOn;
 }
 
 // Per-segment half of the conservative scan filter (see the render kernel's phase 1 and DESIGN.md
@@ -677,13 +686,16 @@ template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy,
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
+#ifndef RRTX_WALK_SLICE
+#define RRTX_WALK_SLICE 4 // cells a lane walks per iteration of the render loop (0: to the end); 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms
+#endif
 #ifndef RRTX_ACCEL_WAVES
-#define RRTX_ACCEL_WAVES 1 // waves per SIMD the accelerated variants are compiled for (register budget)
+#define RRTX_ACCEL_WAVES 6 // waves per SIMD the accelerated fp32 variants are compiled for (80 VGPRs: 43.6 vs 45.5 ms without the limit)
 #endif
 // ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
 // and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
 // rays the grid is not proven for.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? RRTX_ACCEL_WAVES : 1)) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 && sizeof(F) == 4 ? RRTX_ACCEL_WAVES : 1)) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -741,6 +753,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
     Rng rng = {0, 0, 0};
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t plist_count = 0xFFFFu; // header of the current pixel's camera-ray list
+    // ACCEL: a grid walk in progress (see accel_closest_hit)
+    bool in_walk = false;
+    uint32_t walk_cell = 0;
+    F walk_t_out = 0;
+    HitInfo<F> best = {Limits<F>::inf(), -1}; // (lives across iterations only while a walk is in progress)
     int list_passes_done = 0;        // wave-uniform: consecutive LIST passes so far
 #ifdef RRTX_DIAG // timing diagnostics (never in the product build): per-wave real-time stamps
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
@@ -910,7 +927,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         // at most `list_passes` such passes (sky hits regenerate, so a lane may need several) a SCAN pass
         // runs the 488-sphere scan for every lane, by then almost all on secondary rays.  Every segment
         // is still intersected exactly once with the exact test in primitive order: same image.
-        const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0;
+        const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0 && !(ACCEL != 0 && in_walk);
         const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
         list_passes_done = list_pass ? list_passes_done + 1 : 0;
 
@@ -922,11 +939,13 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             }
             else {
             // ---------------- closest hit: hittable_list.h:95-117 ---------------------------------
-            n_segments += 1;
+            if (!(ACCEL != 0 && in_walk)) n_segments += 1;
             const F a = vlen2<F>(path.d); // sphere.h:36
-            HitInfo<F> best;
-            best.t = Limits<F>::inf();
-            best.idx = -1;
+            if (!(ACCEL != 0 && in_walk)) {
+                best.t = Limits<F>::inf();
+                best.idx = -1;
+            }
+            bool still_walking = false;
             if (list_pass) {
                 // exact tests in primitive order: listed spheres, then every moving sphere and triangle
                 const auto &C = *cold_params<F>();
@@ -976,24 +995,15 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             bool need_scan = true;
             if (ACCEL != 0) {
                 const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
+                const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.max_steps;
+                int r;
                 if (ACCEL == 2)
-                    need_scan = !accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best);
+                    r = accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 else
-                    need_scan = !accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best);
-#ifdef RRTX_EXP_WALK_TWICE // experiment: the cost of the walk = the time this adds
-                {
-                    HitInfo<F> again;
-                    again.t = Limits<F>::inf(), again.idx = -1;
-                    Path<F> p2 = path;
-                    p2.o.x += (F)1e-30f * (F)best.idx; // (defeats common-subexpression elimination; changes nothing)
-                    if (ACCEL == 2)
-                        accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, p2, a, t_min, again);
-                    else
-                        accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, p2, a, t_min, again);
-                    if (again.idx == -12345) best.t = again.t;
-                }
-#endif
-                if (VERIFY && !need_scan) { // test build of the kernel: the walk must reproduce the full sequential scan
+                    r = accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
+                need_scan = r == kWalkNeedsScan;
+                still_walking = in_walk = r == kWalkGoesOn;
+                if (VERIFY && !need_scan && !still_walking) { // test build of the kernel: the walk must reproduce the full sequential scan
                     HitInfo<F> full;
                     full.t = Limits<F>::inf();
                     full.idx = -1;
@@ -1152,7 +1162,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             } // scan pass
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
-            done = shade<F>(P, best, path, rng, radiance);
+            if (!still_walking) done = shade<F>(P, best, path, rng, radiance);
             } // max_depth > 0
 
             if (done) {
