@@ -38,10 +38,10 @@ $(LIB): $(OBJS)
 
 # drop-in binaries: `rrt` (float) and `rrtd` (double) — same source, precision chosen by name
 rrt: $(CSRC)/rrt_main.cpp $(LIB) include/rrtx.h
-	$(CXX) $(HOSTFLAGS) -fPIE $< -o $@ -Lrrt_amd -lrrtx -Wl,-rpath,'$$ORIGIN/rrt_amd'
+	$(CXX) $(HOSTFLAGS) -fPIE -pthread $< -o $@ -Lrrt_amd -lrrtx -Wl,-rpath,'$$ORIGIN/rrt_amd'
 
 rrtd: $(CSRC)/rrt_main.cpp $(LIB) include/rrtx.h
-	$(CXX) $(HOSTFLAGS) -fPIE -DRRTX_DOUBLE $< -o $@ -Lrrt_amd -lrrtx -Wl,-rpath,'$$ORIGIN/rrt_amd'
+	$(CXX) $(HOSTFLAGS) -fPIE -pthread -DRRTX_DOUBLE $< -o $@ -Lrrt_amd -lrrtx -Wl,-rpath,'$$ORIGIN/rrt_amd'
 
 oracle:
 	$(MAKE) -C oracle all ref

@@ -4,6 +4,10 @@
 //
 // Flags (recognised by their second character, as main.cpp:69-119 does):
 //   -i file.txt  -o file.png  -w W  -h H  -s spp  -d max_depth  -b  -tx N  -ty N  -q  -D device
+// Several -i (each with its own -o, paired in order) render a batch of scenes in one process: the device
+// context is created once, and while scene k + 1 is parsed, uploaded and rendered, a worker thread
+// quantises and encodes scene k (the reference's README lists "input list of
+// scenes to render" as an idea, README.md:64).
 // Additions of this implementation (no collision with the reference's letters):
 //   -C <samples per work item>   (0 = automatic, -1 = one item per pixel: reference sum order)
 //   -S <seed>                    (RNG base seed, default 1984)
@@ -15,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <future>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -35,7 +41,7 @@ static void usage(const char *arg)
 {
     std::cerr << "Unexpected argument: " << arg << "\n\n";
     std::cerr << "Usage: rrt [options]\n";
-    std::cerr << "  -i file.txt         : input scene file\n";
+    std::cerr << "  -i file.txt         : input scene file (repeat -i / -o pairs to render a batch in one process)\n";
     std::cerr << "  -o file.png         : output raytraced PNG image (default is PPM to stdout)\n";
     std::cerr << "  -w <width>          : output image width. (default = 1200)\n";
     std::cerr << "  -h <height>         : output image height. (800)\n";
@@ -94,8 +100,8 @@ int main(int argc, char *argv[])
     prm.shard_count = 1;
     prm.tile_rows = 4;
     prm.collect_stats = 1;
-    std::string scene_file;
-    const char *png_file = nullptr;
+    std::vector<std::string> scene_files;
+    std::vector<const char *> png_files;
 
     for (int i = 1; i < argc; ++i) {
         if (argv[i][0] != '-') usage(argv[i]);
@@ -104,8 +110,8 @@ int main(int argc, char *argv[])
             return argv[++i];
         };
         switch (argv[i][1]) {
-        case 'i': scene_file = next(); break;
-        case 'o': png_file = next(); break;
+        case 'i': scene_files.push_back(next()); break;
+        case 'o': png_files.push_back(next()); break;
         case 'w': prm.image_width = atoi(next()); break;
         case 'h': prm.image_height = atoi(next()); break;
         case 's': prm.samples_per_pixel = atoi(next()); break;
@@ -130,81 +136,91 @@ int main(int argc, char *argv[])
         }
     }
 
-    if (scene_file.empty()) {
+    if (scene_files.empty()) {
         std::cerr << "ERROR: no scene loaded." << std::endl;
         return 1;
     }
 
-    rrtx_scene *scene = nullptr;
-    int rc = rrtx_scene_load(scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
-    if (rc) {
-        int code = rrtx_scene_exit_code();
-        return code ? code : 1;
-    }
-    int32_t counts[6];
-    rrtx_scene_counts(scene, counts);
-    rrtx_scene_desc desc;
-    rrtx_scene_describe(scene, &desc);
-    // scene.h:443-451
-    std::cerr << "read scene file: " << scene_file << "\n";
-    std::cerr << "material count:  " << counts[0] << "\n";
-    std::cerr << "sphere count:    " << counts[1] << std::endl;
-    std::cerr << "msphere count:   " << counts[2] << std::endl;
-    std::cerr << "obj count:       " << counts[4] << std::endl;
-    std::cerr << "obj_inst count:  " << counts[5] << std::endl;
-    {
-        const fp_t *cam = (const fp_t *)desc.camera;
-        if (cam[22] != cam[23]) std::cerr << "camera time:     " << cam[22] << " - " << cam[23] << std::endl;
-    }
-
-    std::time_t render_time = std::time(nullptr);
-    std::tm render_tm = *std::localtime(&render_time);
-
     rrtx_ctx *ctx = nullptr;
-    rc = rrtx_create(&prm, &ctx);
-    if (rc) die_device(rc);
-    rc = rrtx_set_scene(ctx, &desc);
-    if (rc) die_device(rc);
+    std::future<int> writer; // the previous scene's quantise + encode, running beside this scene's render
+    int exit_code = 0;
+    for (size_t job = 0; job < scene_files.size(); ++job) {
+        const std::string &scene_file = scene_files[job];
+        const char *png_file = job < png_files.size() ? png_files[job] : nullptr;
+        rrtx_scene *scene = nullptr;
+        int rc = rrtx_scene_load(scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
+        if (rc) {
+            if (writer.valid()) writer.get();
+            int code = rrtx_scene_exit_code();
+            return code ? code : 1;
+        }
+        int32_t counts[6];
+        rrtx_scene_counts(scene, counts);
+        rrtx_scene_desc desc;
+        rrtx_scene_describe(scene, &desc);
+        // scene.h:443-451
+        std::cerr << "read scene file: " << scene_file << "\n";
+        std::cerr << "material count:  " << counts[0] << "\n";
+        std::cerr << "sphere count:    " << counts[1] << std::endl;
+        std::cerr << "msphere count:   " << counts[2] << std::endl;
+        std::cerr << "obj count:       " << counts[4] << std::endl;
+        std::cerr << "obj_inst count:  " << counts[5] << std::endl;
+        {
+            const fp_t *cam = (const fp_t *)desc.camera;
+            if (cam[22] != cam[23]) std::cerr << "camera time:     " << cam[22] << " - " << cam[23] << std::endl;
+        }
 
-    std::vector<fp_t> fb((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
-    // rrt.cu:195-202,261
-    std::cerr << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
-    std::cerr << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
-    rrtx_stats st;
-    std::memset(&st, 0, sizeof st);
-    std::cerr << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
-    std::cerr << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
-    std::cerr << "HIP Device: " << prm.device << std::endl;
+        std::time_t render_time = std::time(nullptr);
+        std::tm render_tm = *std::localtime(&render_time);
 
-    rc = rrtx_render(ctx, fb.data(), &st);
-    if (rc) die_device(rc);
+        if (!ctx) {
+            rc = rrtx_create(&prm, &ctx);
+            if (rc) die_device(rc);
+        }
+        rc = rrtx_set_scene(ctx, &desc);
+        if (rc) die_device(rc);
 
-    const double seconds = st.kernel_ms / 1000.0;
-    std::cerr << "took " << seconds << " seconds.\n";
-    char hostname[HOST_NAME_MAX + 1];
-    hostname[0] = 0;
-    gethostname(hostname, sizeof hostname);
-    char when[128];
-    std::strftime(when, sizeof when, "%c %Z,", &render_tm);
-    // rrt.cu:312-315: stats,<date>,<host>,<runtime>,<fp>,w,h,spp,blocks,tx,ty,seconds
-    std::cerr << "stats," << when << hostname << ",HIP" << rrtx_runtime_version() << "," << kFpName << "," << prm.image_width << "," << prm.image_height << ","
-              << prm.samples_per_pixel << "," << st.grid_blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
-    if (seconds > 0)
-        std::cerr << "rate," << (double)st.samples / seconds / 1e6 << " Msamples/s," << st.segments << " segments," << st.prim_tests << " primitive tests,"
-                  << (double)st.bytes_algorithmic / seconds / 1e9 << " GB/s algorithmic," << (st.accel_cells ? "grid of " + std::to_string(st.accel_cells) + " cells" : std::string("list scan")) << "\n";
+        // (owned by the writer task afterwards)
+        auto fb = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+        // rrt.cu:195-202,261
+        std::cerr << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
+        std::cerr << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
+        rrtx_stats st;
+        std::memset(&st, 0, sizeof st);
+        std::cerr << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
+        std::cerr << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
+        std::cerr << "HIP Device: " << prm.device << std::endl;
 
-    std::vector<uint8_t> rgb((size_t)prm.image_width * prm.image_height * 3);
-    rrtx_quantise(fb.data(), kFp64, prm.image_width, prm.image_height, prm.samples_per_pixel, rgb.data());
-    if (png_file == nullptr)
-        rc = rrtx_write_ppm(nullptr, rgb.data(), prm.image_width, prm.image_height);
-    else
-        rc = rrtx_write_png(png_file, rgb.data(), prm.image_width, prm.image_height);
-    if (rc) {
-        std::cerr << "ERROR: could not write image\n";
-        return 1;
+        rc = rrtx_render(ctx, fb->data(), &st);
+        if (rc) die_device(rc);
+
+        const double seconds = st.kernel_ms / 1000.0;
+        std::cerr << "took " << seconds << " seconds.\n";
+        char hostname[HOST_NAME_MAX + 1];
+        hostname[0] = 0;
+        gethostname(hostname, sizeof hostname);
+        char when[128];
+        std::strftime(when, sizeof when, "%c %Z,", &render_tm);
+        // rrt.cu:312-315: stats,<date>,<host>,<runtime>,<fp>,w,h,spp,blocks,tx,ty,seconds
+        std::cerr << "stats," << when << hostname << ",HIP" << rrtx_runtime_version() << "," << kFpName << "," << prm.image_width << "," << prm.image_height << ","
+                  << prm.samples_per_pixel << "," << st.grid_blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
+        if (seconds > 0)
+            std::cerr << "rate," << (double)st.samples / seconds / 1e6 << " Msamples/s," << st.segments << " segments," << st.prim_tests << " primitive tests,"
+                      << (double)st.bytes_algorithmic / seconds / 1e9 << " GB/s algorithmic," << (st.accel_cells ? "grid of " + std::to_string(st.accel_cells) + " cells" : std::string("list scan")) << "\n";
+        rrtx_scene_free(scene);
+
+        // main.cpp:140-162: quantise, flip, write — off the render path: it overlaps the next scene
+        if (writer.valid() && writer.get()) exit_code = 1; // (keeps the outputs in order, PPMs on stdout included)
+        const int w = prm.image_width, h = prm.image_height, spp = prm.samples_per_pixel;
+        writer = std::async(std::launch::async, [fb, png_file, w, h, spp]() -> int {
+            std::vector<uint8_t> rgb((size_t)w * h * 3);
+            rrtx_quantise(fb->data(), kFp64, w, h, spp, rgb.data());
+            const int wrc = png_file == nullptr ? rrtx_write_ppm(nullptr, rgb.data(), w, h) : rrtx_write_png(png_file, rgb.data(), w, h);
+            if (wrc) std::cerr << "ERROR: could not write image\n";
+            return wrc;
+        });
     }
-
-    rrtx_destroy(ctx);
-    rrtx_scene_free(scene);
-    return 0;
+    if (writer.valid() && writer.get()) exit_code = 1;
+    if (ctx) rrtx_destroy(ctx);
+    return exit_code;
 }

@@ -274,6 +274,43 @@ def test_cli_matches_the_library(gpu, tmp_path):
     assert np.array_equal(np.asarray(Image.open(str(png))), gpu.quantise(fb64, spp))
 
 
+def test_cli_renders_a_batch_of_scenes_in_one_process(gpu, tmp_path):
+    """repeated -i / -o pairs share one device context; each image equals the
+    one a separate process writes, in both modes, and a PPM batch comes out on stdout in order."""
+    from PIL import Image
+
+    w, h, spp = 120, 80, 5
+    exe = os.path.join(ROOT, "rrt")
+    names = ["final", "test2", "final", "test3"]
+    single = {}
+    for n in set(names):
+        fb, _ = _render(gpu, SCENES[n], w, h, spp)
+        single[n] = gpu.quantise(fb, spp)
+    outs = [str(tmp_path / ("o%d.png" % i)) for i in range(len(names))]
+    args = [exe, "-w", str(w), "-h", str(h), "-s", str(spp)]
+    for n, o in zip(names, outs):
+        args += ["-i", SCENES[n], "-o", o]
+    for extra in ([], ["-b"]):
+        for o in outs:
+            if os.path.exists(o):
+                os.remove(o)
+        r = subprocess.run(args + extra, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stderr.count(b"took ") == len(names) and r.stdout == b""
+        for n, o in zip(names, outs):
+            assert np.array_equal(np.asarray(Image.open(o)), single[n]), (n, extra)
+    r = subprocess.run([exe, "-w", str(w), "-h", str(h), "-s", str(spp), "-i", SCENES["test1"], "-i", SCENES["test3"]], capture_output=True)
+    assert r.returncode == 0
+    tok = r.stdout.split()
+    per = 4 + w * h * 3
+    assert len(tok) == 2 * per and tok[per] == b"P3"
+    assert np.array_equal(np.array([int(x) for x in tok[per + 4:]], dtype=np.uint8).reshape(h, w, 3), single["test3"])
+    # a bad scene in the middle: the reference's exit code, the earlier outputs are complete
+    r = subprocess.run([exe, "-w", str(w), "-h", str(h), "-s", "1", "-i", SCENES["test1"], "-o", outs[0], "-i", str(tmp_path / "missing.txt"), "-o", outs[1]], capture_output=True)
+    assert r.returncode == 2
+    assert np.asarray(Image.open(outs[0])).shape == (h, w, 3)
+
+
 # ---- scan variants: every operand source / filter / tail combination is the same image ------------
 
 
