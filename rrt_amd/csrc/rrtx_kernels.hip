@@ -686,6 +686,9 @@ template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy,
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
+#ifndef RRTX_ACCEL_WAVES_F64
+#define RRTX_ACCEL_WAVES_F64 4 // ... and the fp64 ones (127 VGPRs: 66.9 vs 72.5 ms at spp 504; the fp64 list scan takes 128.2)
+#endif
 #ifndef RRTX_WALK_SLICE
 #define RRTX_WALK_SLICE 4 // cells a lane walks per iteration of the render loop (0: to the end); 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms
 #endif
@@ -695,7 +698,7 @@ template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy,
 // ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
 // and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
 // rays the grid is not proven for.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 && sizeof(F) == 4 ? RRTX_ACCEL_WAVES : 1)) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : 1)) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
