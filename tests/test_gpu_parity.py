@@ -422,6 +422,11 @@ def test_scene_larger_than_the_lds_copy(gpu, tmp_path):
         fo, so = Oracle(f, 48, 30, fp64).render(3, 50, 1984, order=1)
         assert np.array_equal(fb, fo), fp64
         assert st["segments"] == so["segments"] and st["prim_tests"] == so["prim_tests"]
+        # ... and the acceleration grid of such a scene does not fit the LDS either: tables read from HBM
+        fa, sa = _render(gpu, f, 48, 30, 3, fp64=fp64, sample_chunk=-1, use_bvh=True)
+        assert sa["accel_cells"] > 0 and np.array_equal(fa, fo), fp64
+        fa, sa = _render(gpu, f, 48, 30, 3, fp64=fp64, sample_chunk=-1, use_bvh=True, flags=32)
+        assert sa["list_mismatches"] == 0 and np.array_equal(fa, fo), fp64
 
 
 # ---- camera-ray candidate lists ----------------------------------------------------------------------
