@@ -576,8 +576,10 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     F inv[3], tmax[3];
     int ci[3];
     F t_out = walk_t_out;
+    // (a component too small for 1 / d to be finite counts as parallel: (x - o) * inf would be NaN for x == o)
+    bool par[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) inv[k] = d[k] != 0 ? (F)1 / d[k] : Limits<F>::inf();
+    for (int k = 0; k < 3; ++k) par[k] = !(ffabs(d[k]) >= Limits<F>::coop_tiny()), inv[k] = par[k] ? Limits<F>::inf() : (F)1 / d[k];
     if (!resume) {
         {
             // the rays the unordered rule is proven for
@@ -602,7 +604,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const F glo = P.grid.gmin[k] - fat, ghi = P.grid.gmax[k] + fat;
-            if (d[k] != 0) {
+            if (!par[k]) {
                 const F t1 = (glo - o[k]) * inv[k], t2 = (ghi - o[k]) * inv[k];
                 const F lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
                 t_in = lo > t_in ? lo : t_in;
@@ -628,7 +630,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     // the DDA's per-axis distances to the next cell boundary (from the cell, not accumulated: a resumed
     // walk must not depend on where it was interrupted)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) tmax[k] = d[k] != 0 ? (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k] : Limits<F>::inf();
+    for (int k = 0; k < 3; ++k) tmax[k] = par[k] ? Limits<F>::inf() : (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k];
     const F dtx = P.grid.cell[0] * ffabs(inv[0]), dty = P.grid.cell[1] * ffabs(inv[1]), dtz = P.grid.cell[2] * ffabs(inv[2]);
     const int sx = dx > 0 ? 1 : -1, sy = dy > 0 ? 1 : -1, sz = dz > 0 ? 1 : -1;
     // (a single loop whose trips either test a primitive or step a cell was tried: 59.9 vs 52.6 ms)
