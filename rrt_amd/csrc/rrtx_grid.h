@@ -1,0 +1,209 @@
+// Host side of the accelerated closest hit: builds the uniform grid + always-list that
+// accel_closest_hit (rrtx_path.h) walks.  Header-only so that tests/path_host_check.cpp can build grids
+// and walk them on the CPU with the very code the library and the kernel use.
+#ifndef RRTX_GRID_H
+#define RRTX_GRID_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "rrtx_device.h"
+
+namespace rrtx {
+
+// ---------------------------------------------------------------------------------------------
+// Acceleration grid for use_bvh != 0 (device side: accel_closest_hit).
+//
+// Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2 x their median
+// extent; measured on final.txt: 1.5 / 2 / 2.5 / 3.5 -> 53.2 / 49.5 / 51.5 / 74 ms at spp 504); primitives
+// larger than 1.6 cells, spheres smaller than a fiftieth of a cell and all triangles go into the
+// "always" list.  Every gridded primitive is entered into all cells its box, INFLATED, overlaps.
+// By how much: the reference's discriminant, evaluated in floating point, can be >= 0 only if the
+// ray's line passes within sqrt(r^2 + m) of the centre, m = 32 eps (|o - c|^2 + r^2) (a bound on the
+// rounding error of (oc.d)^2 - |d|^2 (|oc|^2 - r^2) relative to |d|^2; 24 eps by the usual gamma_n
+// accounting), and the root it then reports lies within sqrt(m) of the sphere along the ray.  The grid
+// answers rays that start within `far` of its centre (six half diagonals, three if that blows a
+// typical box up by more than a tenth of a cell; always past the camera), so primitive p gets
+// delta_p = sqrt(r_p^2 + m_p) - r_p + 0.01 cell with |o - c| <= far + half diagonal in m_p: small
+// spheres grow more than large ones, and what would grow by more than half a cell joins the always
+// list.  A primitive whose test can succeed is then always found in a cell the ray's exact line
+// passes through or within delta_p of — and a 3-D DDA that is off by a few ulps at a cell boundary only
+// ever trades a cell the ray grazes by less than that for its neighbour.  Rays starting further away
+// are tested against the grid's box blown up by their own sqrt(m) and, if they touch it, scanned.
+// The walk stops once the next cell begins more than slack0 + slack1 (|o - centre| + half diagonal)
+// beyond the closest hit, slack1 = 1.5 sqrt(32 eps): the along-ray error of a root.
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<SphereCold<F>> &cold, int n_sph, int n_sph_pad, const std::vector<MovingSphereRec<F>> &ms,
+                       int n_msph, int n_tri, const CameraRec<F> &cam, std::vector<uint32_t> &cell_start, std::vector<uint16_t> &cell_prims, std::vector<uint32_t> &always,
+                       GridRec<F> &G)
+{
+    const int msph_base = n_sph_pad, tri_base = n_sph_pad + n_msph;
+    if ((int64_t)tri_base + n_tri >= 65535) return false; // cell lists hold 16-bit primitive indices
+    struct Box {
+        double lo[3], hi[3], r;
+        int idx;
+    };
+    std::vector<Box> boxes;
+    for (int i = 0; i < n_sph; ++i) {
+        Box b;
+        const double cc[3] = {(double)hot[i].cx, (double)hot[i].cy, (double)hot[i].cz}, r = std::fabs((double)cold[i].radius);
+        for (int k = 0; k < 3; ++k) b.lo[k] = cc[k] - r, b.hi[k] = cc[k] + r;
+        b.r = r, b.idx = i;
+        boxes.push_back(b);
+    }
+    for (int i = 0; i < n_msph; ++i) {
+        // centre(tm) = c0 + ((tm - t0) / dt) dc is linear in tm: the hull over the shutter interval is the
+        // hull of its end points (the ray's time is drawn from [time0, time1], camera.h:37)
+        Box b;
+        const double r = std::fabs((double)ms[i].radius);
+        for (int k = 0; k < 3; ++k) b.lo[k] = 1e300, b.hi[k] = -1e300;
+        for (double tm : {(double)cam.time0, (double)cam.time1}) {
+            const double sfrac = (tm - (double)ms[i].t0) / (double)ms[i].dt;
+            for (int k = 0; k < 3; ++k) {
+                const double ck = (double)ms[i].c0[k] + sfrac * (double)ms[i].dc[k];
+                const double pad = 1e-5 * (std::fabs(ck) + r); // the device evaluates the centre in F
+                b.lo[k] = std::min(b.lo[k], ck - r - pad), b.hi[k] = std::max(b.hi[k], ck + r + pad);
+            }
+        }
+        b.r = r, b.idx = msph_base + i;
+        boxes.push_back(b);
+    }
+    if (boxes.size() < 32) return false; // nothing to gain on a handful of primitives
+    std::vector<double> ext;
+    for (const Box &b : boxes) ext.push_back(std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}));
+    std::vector<double> sorted = ext;
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
+    if (!(cell > 0) || !std::isfinite(cell)) return false;
+
+    const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
+    const double cam_o[3] = {(double)cam.origin[0], (double)cam.origin[1], (double)cam.origin[2]};
+    std::vector<double> delta(boxes.size(), 0.0); // per primitive: how far its box is inflated
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        // half diagonal and centre of what would be gridded (by size alone: the inflation comes next)
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        size_t n_sized = 0;
+        for (size_t i = 0; i < boxes.size(); ++i)
+            if (!(ext[i] > 1.6 * cell || boxes[i].r < cell / 50)) {
+                n_sized += 1;
+                for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k]), hi[k] = std::max(hi[k], boxes[i].hi[k]);
+            }
+        if (n_sized < 32) return false;
+        double hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2])) + 0.5 * cell;
+        double cam_dist = 0;
+        for (int k = 0; k < 3; ++k) cam_dist += (cam_o[k] - 0.5 * (lo[k] + hi[k])) * (cam_o[k] - 0.5 * (lo[k] + hi[k]));
+        cam_dist = std::sqrt(cam_dist);
+        // The grid answers rays that start within `far` of its centre: the larger, the fewer rays need the
+        // fat-box test, but the more every box must be inflated.  Six half diagonals if that keeps the
+        // inflation of a typical primitive under a tenth of a cell, else three; always past the camera.
+        double far = 0;
+        bool built = false;
+        for (double mult : {6.0, 3.0}) {
+            far = std::max(mult * hd, 1.25 * cam_dist);
+            const double far_cap = sizeof(F) == 4 ? 1e6 : 1e50;
+            if (far > far_cap) far = far_cap;
+            const double R = far + hd; // |o - c| of any ray the grid answers
+            always.clear();
+            std::vector<double> infl;
+            for (size_t i = 0; i < boxes.size(); ++i) {
+                const double r = boxes[i].r, m = 32 * eps * (R * R + r * r);
+                delta[i] = std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
+                if (ext[i] > 1.6 * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell)
+                    always.push_back((uint32_t)boxes[i].idx);
+                else
+                    infl.push_back(delta[i]);
+            }
+            for (int i = 0; i < n_tri; ++i) always.push_back((uint32_t)(tri_base + i));
+            if (always.size() > 48 || infl.size() < 32) continue;
+            std::nth_element(infl.begin(), infl.begin() + infl.size() / 2, infl.end());
+            if (mult > 3.0 && infl[infl.size() / 2] > 0.1 * cell) continue;
+            built = true;
+            break;
+        }
+        if (!built) {
+            cell *= 1.6; // larger cells: "large" primitives become ordinary, inflations relatively smaller
+            continue;
+        }
+        std::vector<int> gridded;
+        {
+            std::vector<char> is_always(boxes.size(), 0);
+            size_t ai = 0; // always[] was filled in box order
+            for (size_t i = 0; i < boxes.size(); ++i)
+                if (ai < always.size() && always[ai] == (uint32_t)boxes[i].idx) is_always[i] = 1, ++ai;
+            for (size_t i = 0; i < boxes.size(); ++i)
+                if (!is_always[i]) gridded.push_back((int)i);
+        }
+        for (int k = 0; k < 3; ++k) lo[k] = 1e300, hi[k] = -1e300;
+        double slack_max = 0;
+        for (int i : gridded) {
+            slack_max = std::max(slack_max, delta[i]);
+            for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k] - delta[i]), hi[k] = std::max(hi[k], boxes[i].hi[k] + delta[i]);
+        }
+        int dims[3];
+        double total = 1;
+        for (int k = 0; k < 3; ++k) {
+            dims[k] = (int)std::ceil((hi[k] - lo[k]) / cell);
+            if (dims[k] < 1) dims[k] = 1;
+            total *= dims[k];
+        }
+        if (total > 262144.0 || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
+            cell *= 1.6;
+            continue;
+        }
+        hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        // fill
+        const int ncell = dims[0] * dims[1] * dims[2];
+        std::vector<uint32_t> count(ncell + 1, 0);
+        auto range = [&](int i, int k, int &a, int &z) {
+            a = (int)std::floor((boxes[i].lo[k] - delta[i] - lo[k]) / cell), z = (int)std::floor((boxes[i].hi[k] + delta[i] - lo[k]) / cell);
+            a = std::max(a, 0), z = std::min(z, dims[k] - 1);
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i : gridded) {
+                int a[3], z[3];
+                for (int k = 0; k < 3; ++k) range(i, k, a[k], z[k]);
+                for (int iz = a[2]; iz <= z[2]; ++iz)
+                    for (int iy = a[1]; iy <= z[1]; ++iy)
+                        for (int ix = a[0]; ix <= z[0]; ++ix) {
+                            const int cidx = (iz * dims[1] + iy) * dims[0] + ix;
+                            if (pass == 0)
+                                count[cidx + 1] += 1;
+                            else
+                                cell_prims[count[cidx]++] = (uint16_t)boxes[i].idx;
+                        }
+            }
+            if (pass == 0) {
+                for (int q = 0; q < ncell; ++q) count[q + 1] += count[q];
+                cell_start.assign(count.begin(), count.end());
+                cell_prims.assign(count[ncell], 0);
+                if (count[ncell] > 4000000u) return false;
+            }
+        }
+        // within a cell keep primitive order (not needed for correctness; keeps runs deterministic)
+        for (int q = 0; q < ncell; ++q) std::sort(cell_prims.begin() + cell_start[q], cell_prims.begin() + cell_start[q + 1]);
+        for (int k = 0; k < 3; ++k) {
+            G.gmin[k] = (F)lo[k], G.gmax[k] = (F)(lo[k] + dims[k] * cell);
+            G.cell[k] = (F)cell, G.inv_cell[k] = (F)(1.0 / cell);
+            G.dims[k] = dims[k];
+            G.center[k] = (F)(0.5 * (lo[k] + hi[k]));
+        }
+        G.far2 = (F)(far * far);
+        G.slack = (F)(0.01 * cell);              // slack0
+        G.slack1 = (F)(1.5 * std::sqrt(32 * eps)); // times (|o - centre| + half diagonal)
+        G.half_diag = (F)hd;
+        G.max_steps = dims[0] + dims[1] + dims[2] + 3 + (int)cell_prims.size(); // trips of the walk: a cell step or a primitive test each
+        if (getenv("RRTX_DEBUG_GRID"))
+            fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, largest inflation %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],
+                    cell_prims.size(), always.size(), slack_max, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2]);
+        return true;
+    }
+    return false;
+}
+
+} // namespace rrtx
+
+#endif
