@@ -24,7 +24,7 @@ all: default oracle
 $(CSRC)/rrtx_kernels.o: $(CSRC)/rrtx_kernels.hip $(CSRC)/rrtx_device.h $(CSRC)/rrtx_path.h
 	$(HIPCC) $(KFLAGS) -c $< -o $@
 
-$(CSRC)/rrtx_api.o: $(CSRC)/rrtx_api.cpp $(CSRC)/rrtx_device.h $(CSRC)/rrtx_grid.h $(CSRC)/rrtx_launch.h include/rrtx.h
+$(CSRC)/rrtx_api.o: $(CSRC)/rrtx_api.cpp $(CSRC)/rrtx_device.h $(CSRC)/rrtx_grid.h $(CSRC)/rrtx_pack.h $(CSRC)/rrtx_launch.h include/rrtx.h
 	$(HIPCC) $(HOSTFLAGS) -c $< -o $@
 
 $(CSRC)/host_scene.o: $(CSRC)/host_scene.cpp include/rrtx.h

@@ -15,6 +15,7 @@
 
 #include "../../include/rrtx.h"
 #include "rrtx_grid.h"
+#include "rrtx_pack.h"
 #include "rrtx_launch.h"
 
 namespace {
@@ -39,22 +40,6 @@ int fail(int code, const std::string &msg)
             return fail(RRTX_E_DEVICE, buf_);                                                                            \
         }                                                                                                                \
     } while (0)
-
-template <typename F> struct RefTypes;
-template <> struct RefTypes<float> {
-    typedef rrtx_camera_f32 camera;
-    typedef rrtx_material_f32 material;
-    typedef rrtx_sphere_f32 sphere;
-    typedef rrtx_moving_sphere_f32 moving_sphere;
-    typedef rrtx_triangle_f32 triangle;
-};
-template <> struct RefTypes<double> {
-    typedef rrtx_camera_f64 camera;
-    typedef rrtx_material_f64 material;
-    typedef rrtx_sphere_f64 sphere;
-    typedef rrtx_moving_sphere_f64 moving_sphere;
-    typedef rrtx_triangle_f64 triangle;
-};
 
 constexpr int kEventRing = 64;
 
@@ -127,135 +112,18 @@ int rows_of_shard(const rrtx_params &p, std::vector<int32_t> *out)
     return count;
 }
 
-template <typename F> void pack_unit(const F v[3], F out[3])
-{
-    // vec3.h:125 unit_vector = (1/len) * v
-    F len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    F inv = (F)1 / len;
-    out[0] = inv * v[0], out[1] = inv * v[1], out[2] = inv * v[2];
-}
-
 template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
 {
-    typedef RefTypes<F> R;
-    const typename R::camera *cam = (const typename R::camera *)s->camera;
-    const typename R::material *mats = (const typename R::material *)s->materials;
-    const typename R::sphere *sph = (const typename R::sphere *)s->spheres;
-    const typename R::moving_sphere *msp = (const typename R::moving_sphere *)s->moving_spheres;
-    const typename R::triangle *tri = (const typename R::triangle *)s->triangles;
-
-    // camera.h:43-48 has the same member order as CameraRec
-    static_assert(sizeof(typename R::camera) == sizeof(CameraRec<F>), "camera layout");
-    memcpy(c->cam_bytes, cam, sizeof(CameraRec<F>));
-
-    // materials: what create_world builds (rrt.cu:137-148; material.h:19,48,74)
-    std::vector<MaterialRec<F>> hmat(s->num_materials > 0 ? s->num_materials : 1);
-    for (int i = 0; i < s->num_materials; ++i) {
-        MaterialRec<F> m = {};
-        m.type = mats[i].type;
-        if (mats[i].type == RRTX_LAMBERTIAN) {
-            m.r = mats[i].mat.lambertian.albedo[0], m.g = mats[i].mat.lambertian.albedo[1], m.b = mats[i].mat.lambertian.albedo[2];
-        }
-        else if (mats[i].type == RRTX_METAL) {
-            m.r = mats[i].mat.metal.albedo[0], m.g = mats[i].mat.metal.albedo[1], m.b = mats[i].mat.metal.albedo[2];
-            F f = (F)mats[i].mat.metal.fuzz;
-            m.param = f < (F)1.0 ? f : (F)1.0;
-        }
-        else if (mats[i].type == RRTX_DIELECTRIC) {
-            m.param = (F)mats[i].mat.dielectric.ref_idx;
-        }
-        else
-            return fail(RRTX_E_INVALID, "rrtx_set_scene: unknown material type");
-        hmat[i] = m;
-    }
-
-    auto check_mat = [&](int idx) { return idx >= 0 && idx < s->num_materials; };
-
-    // spheres: hot {center, r*r} + cold {r, material}; padded with never-hit records
-    const int pad = kSpherePad;
-    const int n_pad = ((s->num_spheres + pad - 1) / pad) * pad;
-    std::vector<SphereHot<F>> hhot(n_pad > 0 ? n_pad : 1);
-    std::vector<SphereCold<F>> hcold(n_pad > 0 ? n_pad : 1);
-    for (int i = 0; i < n_pad; ++i) {
-        if (i < s->num_spheres) {
-            if (!check_mat(sph[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: sphere material index out of range");
-            F r = (F)sph[i].radius; // sphere(cen, FP_T r, m), sphere.h:11
-            hhot[i].cx = sph[i].center[0], hhot[i].cy = sph[i].center[1], hhot[i].cz = sph[i].center[2];
-            hhot[i].r2 = r * r; // sphere.h:38
-            hcold[i].radius = r;
-            hcold[i].mat = sph[i].material_idx;
-        }
-        else {
-            // c = |oc|^2 + inf => discriminant = -inf: never a candidate (and phase 2 skips k >= n_sph)
-            hhot[i].cx = hhot[i].cy = hhot[i].cz = 0;
-            hhot[i].r2 = -std::numeric_limits<F>::infinity();
-            hcold[i].radius = 1;
-            hcold[i].mat = 0;
-        }
-    }
-    // Conservative scan filter table {c, thr}: thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), evaluated in
-    // double (long double for fp64) and rounded DOWN, so the device-side test can only err towards
-    // "candidate".  The filter's error bound assumes finite, not absurdly scaled magnitudes; scenes
-    // outside that range use the exact scan.
-    std::vector<SphereHot<F>> hfil(n_pad > 0 ? n_pad : 1);
-    bool filter_ok = true;
-    {
-        const long double eps = sizeof(F) == 4 ? 0x1p-24L : 0x1p-53L;
-        const long double big = sizeof(F) == 4 ? 1e30L : 1e280L, tiny = sizeof(F) == 4 ? 1e-25L : 1e-250L;
-        for (int i = 0; i < n_pad; ++i) {
-            hfil[i].cx = hhot[i].cx, hfil[i].cy = hhot[i].cy, hfil[i].cz = hhot[i].cz;
-            if (i >= s->num_spheres) {
-                hfil[i].r2 = std::numeric_limits<F>::infinity(); // finite test values are always below it
-                continue;
-            }
-            const long double cx = hhot[i].cx, cy = hhot[i].cy, cz = hhot[i].cz, r2 = hhot[i].r2;
-            const long double c2 = cx * cx + cy * cy + cz * cz;
-            if (!(std::isfinite((double)c2) && std::isfinite((double)r2)) || !(c2 + r2 <= big) || !(c2 + r2 >= tiny)) filter_ok = false;
-            const long double thr = (c2 - r2) - (long double)kFilterK * eps * (c2 + r2);
-            F t = (F)thr;
-            if ((long double)t > thr) t = std::nextafter(t, -std::numeric_limits<F>::infinity());
-            t = std::nextafter(t, -std::numeric_limits<F>::infinity()); // one more ulp of slack
-            hfil[i].r2 = t;
-        }
-    }
-    std::vector<MovingSphereRec<F>> hms(s->num_moving_spheres > 0 ? s->num_moving_spheres : 1);
-    for (int i = 0; i < s->num_moving_spheres; ++i) {
-        if (!check_mat(msp[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: moving sphere material index out of range");
-        MovingSphereRec<F> m = {};
-        F t0 = (F)msp[i].time0, t1 = (F)msp[i].time1, r = (F)msp[i].radius; // moving_sphere.h:11-12
-        for (int k = 0; k < 3; ++k) {
-            m.c0[k] = msp[i].center0[k];
-            m.dc[k] = msp[i].center1[k] - msp[i].center0[k];
-        }
-        m.t0 = t0;
-        m.dt = t1 - t0;
-        m.r2 = r * r;
-        m.radius = r;
-        m.mat = msp[i].material_idx;
-        hms[i] = m;
-    }
-    std::vector<TriangleRec<F>> htri(s->num_triangles > 0 ? s->num_triangles : 1);
-    for (int i = 0; i < s->num_triangles; ++i) {
-        if (!check_mat(tri[i].material_idx)) return fail(RRTX_E_INVALID, "rrtx_set_scene: triangle material index out of range");
-        TriangleRec<F> t = {};
-        F e1[3], e2[3], u1[3], u2[3], cr[3];
-        for (int k = 0; k < 3; ++k) {
-            t.v0[k] = tri[i].vertices[0][k];
-            e1[k] = tri[i].vertices[1][k] - tri[i].vertices[0][k];
-            e2[k] = tri[i].vertices[2][k] - tri[i].vertices[0][k];
-            t.e1[k] = e1[k];
-            t.e2[k] = e2[k];
-        }
-        // triangle.h:9-15: unit(cross(unit(v1-v0), unit(v2-v0)))
-        pack_unit<F>(e1, u1);
-        pack_unit<F>(e2, u2);
-        cr[0] = u1[1] * u2[2] - u1[2] * u2[1];
-        cr[1] = u1[2] * u2[0] - u1[0] * u2[2];
-        cr[2] = u1[0] * u2[1] - u1[1] * u2[0];
-        pack_unit<F>(cr, t.n);
-        t.mat = tri[i].material_idx;
-        htri[i] = t;
-    }
+    PackedScene<F> packed;
+    if (const char *what = pack_scene<F>(s, packed)) return fail(RRTX_E_INVALID, what);
+    memcpy(c->cam_bytes, &packed.cam, sizeof(CameraRec<F>));
+    std::vector<MaterialRec<F>> &hmat = packed.mat;
+    std::vector<SphereHot<F>> &hhot = packed.hot, &hfil = packed.filter;
+    std::vector<SphereCold<F>> &hcold = packed.cold;
+    std::vector<MovingSphereRec<F>> &hms = packed.ms;
+    std::vector<TriangleRec<F>> &htri = packed.tri;
+    const int n_pad = packed.n_pad;
+    const bool filter_ok = packed.filter_ok;
 
     RRTX_HIP(hipSetDevice(c->device));
     void *old[6] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat};
@@ -280,22 +148,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
     if ((rc = up(&c->d_mat, hmat.data(), hmat.size() * sizeof(MaterialRec<F>)))) return rc;
-    {
-        // the tail kernel's split scan needs every root to be non-NaN: finite primitives of bounded
-        // magnitude (so that no intermediate of the discriminant overflows)
-        const double lim = sizeof(F) == 4 ? 3e7 : 1e60;
-        bool ok = true;
-        auto chk = [&](double v) { ok = ok && std::isfinite(v) && std::fabs(v) <= lim; };
-        for (int i = 0; i < s->num_spheres; ++i) chk(hhot[i].cx), chk(hhot[i].cy), chk(hhot[i].cz), chk(hcold[i].radius);
-        for (int i = 0; i < s->num_moving_spheres; ++i) {
-            for (int k = 0; k < 3; ++k) chk(hms[i].c0[k]), chk(hms[i].dc[k]);
-            chk(hms[i].t0), chk(hms[i].dt), chk(hms[i].radius);
-            ok = ok && hms[i].dt != 0; // (time - t0) / 0 is where NaN centres come from
-        }
-        for (int i = 0; i < s->num_triangles; ++i)
-            for (int k = 0; k < 3; ++k) chk(htri[i].v0[k]), chk(htri[i].e1[k]), chk(htri[i].e2[k]), chk(htri[i].n[k]);
-        c->tail_ok = ok;
-    }
+    c->tail_ok = packed.tail_ok;
     // accelerated closest hit (the reference's -b switches its BVH off, main.cpp:67,90)
     for (void *p : {(void *)c->d_grid_cell_start, (void *)c->d_grid_cell_prims, (void *)c->d_grid_always})
         if (p) (void)hipFree(p);

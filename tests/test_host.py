@@ -175,3 +175,42 @@ def test_grid_walk_equals_the_sequential_scan_on_the_host(tmp_path):
     r = subprocess.run([str(exe), "400000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" 0 mismatches, 0 sliced-walk mismatches") == 4, r.stdout
+
+
+@pytest.fixture(scope="module")
+def host_render(tmp_path_factory):
+    """tests/path_host_render.cpp: the kernel's path arithmetic (rrtx_path.h) compiled for the host."""
+    exe = tmp_path_factory.mktemp("hostrender") / "path_host_render"
+    lib_dir = os.path.join(ROOT, "rrt_amd")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "path_host_render.cpp"), "-o", str(exe), "-L" + lib_dir, "-lrrtx",
+                    "-Wl,-rpath," + lib_dir], check=True)
+
+    def run(scene, w, h, spp, depth, fp64, chunk, mode):
+        out = str(exe) + ".raw"
+        r = subprocess.run([str(exe), scene, str(w), str(h), str(spp), str(depth), str(int(fp64)), str(chunk), str(mode), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        info = dict(zip(r.stdout.split()[0::2], (int(x) for x in r.stdout.split()[1::2])))
+        return np.fromfile(out, dtype=np.float64 if fp64 else np.float32).reshape(h, w, 3), info
+
+    return run
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+@pytest.mark.parametrize("name", ["test1", "test2", "test3", "final", "xform"])
+def test_kernel_source_compiled_for_the_host_equals_the_oracle(host_render, name, fp64):
+    """The product's own path arithmetic — the headers rrtx_kernels.hip is built from — run on the CPU by a
+    plain loop, against the oracle: bit-identical radiance for every scene, in the list-scan and the
+    grid-walk formulation of the closest hit, with chunked and whole-pixel sums.  (What the GPU tests
+    then add is the kernel's scheduling around this arithmetic.)"""
+    path = os.path.join(GOLDEN, "scenes", "xform.txt") if name == "xform" else scene_path(name)
+    w, h, spp = 40, 26, 5
+    for chunk in (8, 2):
+        want, st = Oracle(path, w, h, fp64).render(spp, 50, 1984, order=1, chunk=min(chunk, spp))
+        for mode in (0, 1):
+            got, info = host_render(path, w, h, spp, 50, fp64, chunk, mode)
+            assert info["segments"] == st["segments"], (chunk, mode)
+            assert np.array_equal(got, want), (chunk, mode)
+            if name == "final":
+                assert (info["grid"] > 0) == (mode == 1) and (mode == 0 or info["walked"] > 0.99 * info["segments"])
+    want, _ = Oracle(path, w, h, fp64).render(3, 2, 1984, order=1, chunk=3)  # depth limit
+    assert np.array_equal(host_render(path, w, h, 3, 2, fp64, -1, 1)[0], want)
