@@ -214,3 +214,29 @@ def test_kernel_source_compiled_for_the_host_equals_the_oracle(host_render, name
                 assert (info["grid"] > 0) == (mode == 1) and (mode == 0 or info["walked"] > 0.99 * info["segments"])
     want, _ = Oracle(path, w, h, fp64).render(3, 2, 1984, order=1, chunk=3)  # depth limit
     assert np.array_equal(host_render(path, w, h, 3, 2, fp64, -1, 1)[0], want)
+
+
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    """Sanitizers run on the CPU build only (the GPU pool has none): the scene parser on every scene
+    and on malformed input, the quantiser and the PNG / PPM writers; and the grid builder + grid walk
+    of the accelerated closest hit (the kernel's source, compiled for the host)."""
+    san = ["-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    csrc = os.path.join(ROOT, "rrt_amd", "csrc")
+    exe = tmp_path / "host_asan"
+    subprocess.run(["g++"] + san + [os.path.join(ROOT, "tests", "sanitize", "host_asan_main.cpp"), os.path.join(csrc, "host_scene.cpp"), os.path.join(csrc, "host_image.cpp"), "-o", str(exe), "-lz"],
+                   check=True)
+    bad = []
+    for i, text in enumerate(["camera 1 2 3 0 0 0 0 1 0 40 0.1 10\nmaterial a lambertian 1 1 1\nsphere 0 0 0\n", "obj_beg 3 1\nobj_vtx 0 0 0\nobj_vtx 1 0 0\nobj_end\n", "material a wood 1 1 1\n",
+                              "camera 1 2 3 0 0 0 0 1 0 40 0.1 10\nmaterial a lambertian 1 1 1\nobj 5 a t 1 2 3\n", ""]):
+        f = tmp_path / ("bad%d.txt" % i)
+        f.write_text(text)
+        bad.append(str(f))
+    scenes = [scene_path(n) for n in ("test1", "test2", "test3", "final")] + [os.path.join(GOLDEN, "scenes", "xform.txt")]
+    r = subprocess.run([str(exe)] + scenes + bad + [str(tmp_path / "missing.txt")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+    assert r.stdout.count("rc=0") == 2 * len(scenes) and "png 0 ppm 0" in r.stdout
+    exe2 = tmp_path / "path_check_asan"
+    subprocess.run(["g++"] + san + [os.path.join(ROOT, "tests", "path_host_check.cpp"), "-o", str(exe2)], check=True)
+    r = subprocess.run([str(exe2), "60000"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
