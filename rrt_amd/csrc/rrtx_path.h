@@ -301,9 +301,12 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
 {
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
     radiance = mk<F>(0, 0, 0);
+    // unit_vector(r.direction()): the sky (rrt.cu:71), metal (material.h:52) and dielectric (material.h:82)
+    // each form it; once here, because a wave with all three kinds of lanes would pay the square root
+    // and the division three times
+    const V3<F> ud = vunit<F>(path.d);
     if (best.idx < 0) {
         // sky, rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50)
-        const V3<F> ud = vunit<F>(path.d);
         const F t = (F)0.5 * (ud.y + (F)1.0);
         const V3<F> c = vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0)));
         radiance = vmul<F>(path.atten, c);
@@ -345,7 +348,6 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
         }
         else {
             // metal, material.h:50-57
-            const V3<F> ud = vunit<F>(path.d);
             const V3<F> reflected = vsub<F>(ud, vscale<F>((F)2 * vdot<F>(ud, n), n)); // vec3.h:156
             new_d = vadd<F>(reflected, vscale<F>(m.param, rs));
             scattered = vdot<F>(new_d, n) > 0;
@@ -355,7 +357,6 @@ template <typename F> RRTX_DEV bool shade(const KernelParams<F> &P, const HitInf
         // dielectric, material.h:76-96
         albedo = mk<F>((F)1.0, (F)1.0, (F)1.0);
         const F ratio = front_face ? ((F)1.0 / m.param) : m.param;
-        const V3<F> ud = vunit<F>(path.d);
         const F cos_theta = ffmin(vdot<F>(vneg<F>(ud), n), (F)1.0);
         const F sin_theta = fsqrt((F)1.0 - cos_theta * cos_theta);
         bool reflect_it = ratio * sin_theta > (F)1.0;
