@@ -100,3 +100,66 @@ class ShardedRenderer:
         if self.world == 1:
             return self.local
         return gather_frame(self.local, self.h, self.tile_rows, self.group, dst)
+
+
+def main(argv=None):
+    """Multi-GPU front end with the reference's flags (main.cpp:69-119): one process per GPU,
+
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+            -m rrt_amd.dist -i scenes/final.txt -o final.png -w 3840 -h 2160 -s 1000
+
+    renders BASELINE.json's 8-GPU configuration: every rank renders its row tiles, one gather over RCCL
+    brings them to rank 0, which quantises and writes the PNG (or the PPM to stdout).  Without a launcher
+    it runs on one GPU.  -b selects the list scan, -T the tile height (default 4); RRTX_DIST_BACKEND=gloo
+    stages the gather through the host (tests, boxes where ranks share a GPU)."""
+    import argparse
+    import os
+    import sys
+
+    ap = argparse.ArgumentParser(prog="python -m rrt_amd.dist", add_help=False)
+    ap.add_argument("-i", dest="scene", required=True)
+    ap.add_argument("-o", dest="png", default=None)
+    ap.add_argument("-w", dest="w", type=int, default=1200)
+    ap.add_argument("-h", dest="h", type=int, default=800)
+    ap.add_argument("-s", dest="spp", type=int, default=10)
+    ap.add_argument("-d", dest="depth", type=int, default=50)
+    ap.add_argument("-b", dest="no_bvh", action="store_true")
+    ap.add_argument("-T", dest="tile_rows", type=int, default=4)
+    ap.add_argument("-S", dest="seed", type=int, default=1984)
+    ap.add_argument("--fp64", action="store_true", help="rrtd: double precision")
+    ap.add_argument("--help", action="help")
+    a = ap.parse_args(argv)
+
+    from .render import quantise, write_png, write_ppm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RRTX_DIST_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    sr = ShardedRenderer(a.scene, a.w, a.h, a.spp, a.depth, fp64=a.fp64, tile_rows=a.tile_rows, seed=a.seed, device=torch.device("cuda", device_index), use_bvh=not a.no_bvh)
+    frame = sr.render()
+    torch.cuda.synchronize()
+    st = sr.rrt.collect()
+    print("rank %d: %d rows, took %g seconds." % (sr.rank, len(sr.rows), st["kernel_ms"] / 1000.0), file=sys.stderr)
+    rc = 0
+    if sr.rank == 0:
+        rgb = quantise(frame.cpu().numpy(), a.spp)
+        if a.png:
+            write_png(a.png, rgb)
+        else:
+            write_ppm(None, rgb)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

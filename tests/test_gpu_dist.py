@@ -100,3 +100,34 @@ def test_sharded_render_across_ranks_equals_the_full_frame(gpu, tmp_path, world,
     r.close()
     assert np.array_equal(got, want)
     assert np.array_equal(want, Oracle(scene_path("final"), w, h, False).render(spp, 50, 1984, order=1, chunk=8)[0])
+
+
+def test_multi_gpu_front_end_writes_the_same_png(gpu, tmp_path):
+    """python -m rrt_amd.dist: the reference's flags, one process per GPU, row-tile shards + one gather.
+    Launched with 3 ranks (sharing this box's GPU, gather staged through gloo) and with none; both
+    PNGs must equal the single-context image, in both closest-hit modes."""
+    import os
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w, h, spp = 120, 90, 6
+    sc = gpu.Scene(scene_path("final"), w, h)
+    r = _list_rrt(gpu, w, h, spp, 50)
+    want = gpu.quantise(r.render(sc), spp)
+    r.close()
+    env = dict(os.environ, RRTX_DIST_BACKEND="gloo", PYTHONPATH=root)
+    for i, extra in enumerate(([], ["-b"])):
+        out = str(tmp_path / ("multi%d.png" % i))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(29631 + i), "-m", "rrt_amd.dist", "-i",
+               scene_path("final"), "-o", out, "-w", str(w), "-h", str(h), "-s", str(spp), "-T", "8"] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert p.stderr.count("took ") == 3
+        assert np.array_equal(np.asarray(Image.open(out)), want), extra
+    out = str(tmp_path / "single.png")
+    p = subprocess.run([sys.executable, "-m", "rrt_amd.dist", "-i", scene_path("final"), "-o", out, "-w", str(w), "-h", str(h), "-s", str(spp)], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert np.array_equal(np.asarray(Image.open(out)), want)
