@@ -118,7 +118,8 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (const char *what = pack_scene<F>(s, packed)) return fail(RRTX_E_INVALID, what);
     memcpy(c->cam_bytes, &packed.cam, sizeof(CameraRec<F>));
     std::vector<MaterialRec<F>> &hmat = packed.mat;
-    std::vector<SphereHot<F>> &hhot = packed.hot, &hfil = packed.filter;
+    std::vector<SphereHot<F>> &hhot = packed.hot;
+    std::vector<SphereHot<float>> &hfil = packed.filter;
     std::vector<SphereCold<F>> &hcold = packed.cold;
     std::vector<MovingSphereRec<F>> &hms = packed.ms;
     std::vector<TriangleRec<F>> &htri = packed.tri;
@@ -139,11 +140,11 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     };
     int rc;
     if ((rc = up(&c->d_hot, hhot.data(), hhot.size() * sizeof(SphereHot<F>)))) return rc;
-    if ((rc = up(&c->d_filter, hfil.data(), hfil.size() * sizeof(SphereHot<F>)))) return rc;
+    if ((rc = up(&c->d_filter, hfil.data(), hfil.size() * sizeof(SphereHot<float>)))) return rc;
     c->use_filter = filter_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN);
     c->lds_mode = 0;
-    if (c->use_filter && hfil.size() * sizeof(SphereHot<F>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
-        c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : (sizeof(F) == 8 ? 0 : 1); // fp64 is VALU-bound on scalar loads alone (measured)
+    if (c->use_filter && hfil.size() * sizeof(SphereHot<float>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
+        c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : 1; // (fp64 too: its filter is the fp32 one)
     if ((rc = up(&c->d_cold, hcold.data(), hcold.size() * sizeof(SphereCold<F>)))) return rc;
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
@@ -186,7 +187,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
 {
     KernelParams<F> P = {};
     P.sph_hot = (const SphereHot<F> *)c->d_hot;
-    P.sph_filter = (const SphereHot<F> *)c->d_filter;
+    P.sph_filter = (const SphereHot<float> *)c->d_filter;
     P.sph_cold = (const SphereCold<F> *)c->d_cold;
     P.msph = (const MovingSphereRec<F> *)c->d_msph;
     P.tri = (const TriangleRec<F> *)c->d_tri;

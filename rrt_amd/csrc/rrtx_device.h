@@ -37,6 +37,10 @@ constexpr uint32_t kTaperBatch = 256; // single-sample tasks per pull, at most (
 // Safety factor of the conservative scan filter, in units of the unit roundoff.  The
 // analytic bound needs about 160; empirically false negatives appear only below 16.
 constexpr int kFilterK = 256;
+// The filter is ALWAYS evaluated in fp32, also for fp64 rays (their fp64 FMAs run at half rate): ray and
+// centres are rounded to float, and the margin covers that rounding too.  Empirically false negatives
+// against the fp64 discriminant vanish at 16 here as well (tests/test_filter_bound.py).
+constexpr int kFilterK64 = 512;
 // A wave of the render kernel hands its unfinished items to the tail kernel once the queue is dry and
 // at most this many of its lanes are alive (break-even of one-ray-per-wave against one-ray-per-lane).
 constexpr int kHandoffLanes = 7;
@@ -124,7 +128,7 @@ inline FastDiv make_fastdiv(uint32_t d)
 
 template <typename F> struct KernelParams {
     const SphereHot<F> *sph_hot;    // n_sph_padded records {cx, cy, cz, r*r}: the exact test
-    const SphereHot<F> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter
+    const SphereHot<float> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter (fp32 for every F)
     const SphereCold<F> *sph_cold;
     const MovingSphereRec<F> *msph;
     const TriangleRec<F> *tri;

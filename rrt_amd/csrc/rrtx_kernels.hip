@@ -118,9 +118,22 @@ template <typename F> RRTX_DEV const RRTX_CONST_AS KernelParams<F> *cold_params(
     return p;
 }
 
+// Records the scan reads: the fp32 filter table, or (FILTER = false) the exact-test table in F.
+template <typename F, bool FILTER> struct ScanType {
+    typedef F type;
+    static RRTX_DEV const SphereHot<F> *table(const KernelParams<F> &P) { return P.sph_hot; }
+};
+template <typename F> struct ScanType<F, true> {
+    typedef float type;
+    static RRTX_DEV const SphereHot<float> *table(const KernelParams<F> &P) { return P.sph_filter; }
+};
+
 // LDSMODE: where the scan reads its sphere records from.  0 = scalar loads only; 1 = blocks alternate
 // between scalar loads and broadcast reads of a copy in LDS; 2 = LDS only.  At 8 VALU per test the
 // scalar data cache (shared by CUs, ~4.5 B/clk) is the binding unit, which is what the LDS copy relieves.
+#ifndef RRTX_LIST_WAVES_F64
+#define RRTX_LIST_WAVES_F64 5 // waves per SIMD the fp64 list-scan variants are compiled for (94 VGPRs, 12 spilled: 92.4 vs 102.0 ms; 6: 100.1)
+#endif
 #ifndef RRTX_ACCEL_WAVES_F64
 #define RRTX_ACCEL_WAVES_F64 4 // ... and the fp64 ones (127 VGPRs: 66.9 vs 72.5 ms at spp 504; the fp64 list scan takes 128.2)
 #endif
@@ -133,16 +146,17 @@ template <typename F> RRTX_DEV const RRTX_CONST_AS KernelParams<F> *cold_params(
 // ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
 // and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
 // rays the grid is not proven for.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : 1)) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
     constexpr int kCap = ACCEL != 0 ? 8 : kCandCap;
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCap][64];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
-    SphereHot<F> *const sph_lds = (SphereHot<F> *)dyn_lds;
+    typedef typename ScanType<F, FILTER>::type ST; // precision of the scan's records: the filter is fp32 for every F
+    SphereHot<ST> *const sph_lds = (SphereHot<ST> *)dyn_lds;
     if (LDSMODE != 0) {
-        const SphereHot<F> *src = FILTER ? P.sph_filter : P.sph_hot;
+        const SphereHot<ST> *src = ScanType<F, FILTER>::table(P);
         for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) sph_lds[i] = src[i];
         __syncthreads();
     }
@@ -162,10 +176,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
     const int wave = threadIdx.x >> 6;
     uint32_t *const my_cand = &cand_lds[wave][0][lane]; // slot s at my_cand[s * 64]: bank == lane, conflict-free
     const uint32_t my_cand_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)my_cand; // LDS byte address
-    const F zero_sgpr = (F)0;
+    const ST zero_sgpr = (ST)0;
 
-    typedef const RRTX_CONST_AS SphereHot<F> *HotPtr; // constant address space => s_load for uniform indices
-    const HotPtr sph_scalar = (HotPtr)(FILTER ? P.sph_filter : P.sph_hot);
+    typedef const RRTX_CONST_AS SphereHot<ST> *HotPtr; // constant address space => s_load for uniform indices
+    const HotPtr sph_scalar = (HotPtr)ScanType<F, FILTER>::table(P);
 
     const F t_min = (F)0.001; // rrt.cpp:32 typing
     const int n_sph = P.n_sph, n_sph_pad = P.n_sph_padded, n_msph = P.n_msph, n_tri = P.n_tri;
@@ -506,9 +520,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             //   Per segment: n, b = 2(o - s n), g = s^2 - |o|^2 + K eps |o|^2.  Per sphere (SGPRs):
             //   c and thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), rounded down on the host.
             //   candidate  <=>  not (u^2 + b.c + g < thr).   Phase 2 then applies the exact test.
-            FilterRay<F> fr = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
-            if (FILTER) fr = make_filter_ray<F>(path, a); // extreme rays take the always-candidate route: phase 2 is exact
-            constexpr int kUnroll = SphereUnroll<F>::value;
+            FilterRay fr = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
+            if (FILTER) fr = make_filter_ray(path, a); // extreme rays take the always-candidate route: phase 2 is exact
+            constexpr int kUnroll = SphereUnroll<ST>::value;
             // one straight-line block of N tests; FROM_LDS selects the operand source
             auto scan_block = [&](int k0, auto from_lds_c, auto n_c) {
                 constexpr bool FROM_LDS = decltype(from_lds_c)::value != 0;
@@ -516,11 +530,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                 if (__ballot(cnt > (uint32_t)(kCap - N)) != 0ull) drain();
                 // the block's records first (s_load_dwordx16s, or N ds_read_b128 broadcasts), then
                 // N x {test, push}
-                F bcx[N], bcy[N], bcz[N], bw[N];
+                ST bcx[N], bcy[N], bcz[N], bw[N];
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
                     if (FROM_LDS) {
-                        const SphereHot<F> r = sph_lds[k0 + u];
+                        const SphereHot<ST> r = sph_lds[k0 + u];
                         bcx[u] = r.cx, bcy[u] = r.cy, bcz[u] = r.cz, bw[u] = r.r2;
                     }
                     else {
@@ -529,16 +543,16 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                 }
                 auto test = [&](auto uc) {
                     constexpr int u = decltype(uc)::value;
-                    const F cx = bcx[u], cy = bcy[u], cz = bcz[u], r2 = bw[u];
+                    const ST cx = bcx[u], cy = bcy[u], cz = bcz[u], r2 = bw[u];
                     if (FILTER) {
-                        push_if_not_less<u, FROM_LDS>(filter_value<F>(fr, cx, cy, cz), r2, cnt, my_cand_lds, my_cand, k0); // the r2 slot holds thr
+                        push_if_not_less<u, FROM_LDS>(filter_value(fr, (float)cx, (float)cy, (float)cz), (float)r2, cnt, my_cand_lds, my_cand, k0); // the r2 slot holds thr
                     }
                     else {
-                        const F ocx = path.o.x - cx, ocy = path.o.y - cy, ocz = path.o.z - cz;
+                        const F ocx = path.o.x - (F)cx, ocy = path.o.y - (F)cy, ocz = path.o.z - (F)cz;
                         const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;
-                        const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+                        const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - (F)r2;
                         const F disc = half_b * half_b - a * c;
-                        push_if_not_less<u, false>(disc, zero_sgpr, cnt, my_cand_lds, my_cand, k0); // !(disc < 0), sphere.h:41
+                        push_if_not_less<u, false>(disc, (F)zero_sgpr, cnt, my_cand_lds, my_cand, k0); // !(disc < 0), sphere.h:41
                     }
                 };
                 test(IntC<0>());
@@ -659,19 +673,19 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
     // the sphere table is read from a copy in LDS when it fits (the scan is a chain of dependent loads
     // otherwise: ~1 us each from L2 under load)
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    const SphereHot<F> *sph_tab = FILTER ? P.sph_filter : P.sph_hot;
-    const F *r2_tab = &P.sph_hot[0].r2; // FILTER: r*r of the candidates (the centres are in the filter records)
-    int r2_stride = 4;
+    typedef typename ScanType<F, FILTER>::type ST;
+    const SphereHot<ST> *sph_tab = ScanType<F, FILTER>::table(P); // what every lane tests its share against
+    const SphereHot<F> *exact_tab = P.sph_hot;                      // FILTER: the exact-test records of the candidates
     if (LDS) {
-        SphereHot<F> *const copy = (SphereHot<F> *)dyn_lds;
-        F *const r2_copy = (F *)(copy + P.n_sph_padded);
+        SphereHot<ST> *const copy = (SphereHot<ST> *)dyn_lds;
+        SphereHot<F> *const exact_copy = (SphereHot<F> *)(copy + P.n_sph_padded);
         for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) {
             copy[i] = sph_tab[i];
-            if (FILTER) r2_copy[i] = P.sph_hot[i].r2;
+            if (FILTER) exact_copy[i] = P.sph_hot[i];
         }
         __syncthreads();
         sph_tab = copy;
-        if (FILTER) r2_tab = r2_copy, r2_stride = 1;
+        if (FILTER) exact_tab = exact_copy;
     }
     constexpr uint32_t kGroups = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -789,11 +803,11 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
                     // FILTER: the conservative 7-FMA test of the render kernel's phase 1 first, the exact
                     // test (record from HBM) only for its candidates; otherwise the exact test throughout.
                     // (padding records: thr = +inf / r*r = -inf, never a hit)
-                    FilterRay<F> fr = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
-                    if (FILTER) fr = make_filter_ray<F>(path, a);
+                    FilterRay fr = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
+                    if (FILTER) fr = make_filter_ray(path, a);
                     constexpr int U = 4; // loads in flight per lane
                     for (int p0 = sub; p0 < n_sph_pad; p0 += U * G) {
-                        SphereHot<F> g[U];
+                        SphereHot<ST> g[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) g[u] = sph_tab[p0 + u * G < n_sph_pad ? p0 + u * G : 0];
 #pragma unroll
@@ -801,12 +815,13 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
                             const int idx = p0 + u * G;
                             if (idx >= n_sph_pad) continue;
                             if (FILTER) {
-                                if (!(filter_value<F>(fr, g[u].cx, g[u].cy, g[u].cz) < g[u].r2)) { // the r2 slot holds thr
-                                    refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, r2_tab[idx * r2_stride], path, a, t_min, idx, lb);
+                                if (!(filter_value(fr, (float)g[u].cx, (float)g[u].cy, (float)g[u].cz) < (float)g[u].r2)) { // the r2 slot holds thr
+                                    const SphereHot<F> h = exact_tab[idx];
+                                    refine_sphere<F>(h.cx, h.cy, h.cz, h.r2, path, a, t_min, idx, lb);
                                 }
                             }
                             else
-                                refine_sphere<F>(g[u].cx, g[u].cy, g[u].cz, g[u].r2, path, a, t_min, idx, lb);
+                                refine_sphere<F>((F)g[u].cx, (F)g[u].cy, (F)g[u].cz, (F)g[u].r2, path, a, t_min, idx, lb);
                         }
                     }
                     for (int q = sub; q < n_msph; q += G) {
@@ -1025,7 +1040,7 @@ template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
 }
 template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)
 {
-    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
     if (P.grid_cell_start) { // accelerated closest hit; the scan (scalar loads) is its fallback
         const size_t alds = accel_lds_bytes<F>(P);
         if (P.verify_lists) return launch_variant<F, true, 0, true, 1>(P, grid_blocks, 0, stream);
@@ -1054,7 +1069,7 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
 #endif
 template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filter, int grid_blocks, hipStream_t stream)
 {
-    const size_t lds = (size_t)P.n_sph_padded * (sizeof(SphereHot<F>) + (filter ? sizeof(F) : 0));
+    const size_t lds = (size_t)P.n_sph_padded * (filter ? sizeof(SphereHot<float>) + sizeof(SphereHot<F>) : sizeof(SphereHot<F>));
     const bool in_lds = lds <= (size_t)kLdsSceneBytes;
     if (filter && in_lds)
         hipLaunchKernelGGL((tail_kernel<F, RRTX_TAIL_GROUP, true, true>), dim3(grid_blocks), dim3(kBlockThreads), lds, stream, P);
@@ -1079,7 +1094,7 @@ template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const 
 }
 template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool filter, int lds_mode, int *blocks_per_cu)
 {
-    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<F>) : 0;
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
     if (P.grid_cell_start) {
         const size_t alds = accel_lds_bytes<F>(P);
         if (!filter)

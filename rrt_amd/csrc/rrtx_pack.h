@@ -42,7 +42,8 @@ template <typename F> void pack_unit(const F v[3], F out[3])
 
 template <typename F> struct PackedScene {
     std::vector<MaterialRec<F>> mat;
-    std::vector<SphereHot<F>> hot, filter; // exact-test records {c, r*r}; conservative-filter records {c, thr}
+    std::vector<SphereHot<F>> hot;        // exact-test records {c, r*r}
+    std::vector<SphereHot<float>> filter; // conservative-filter records {c, thr}: fp32 for every F
     std::vector<SphereCold<F>> cold;
     std::vector<MovingSphereRec<F>> ms;
     std::vector<TriangleRec<F>> tri;
@@ -114,30 +115,31 @@ template <typename F> const char *pack_scene(const rrtx_scene_desc *s, PackedSce
             hcold[i].mat = 0;
         }
     }
-    // Conservative scan filter table {c, thr}: thr = |c|^2 - r^2 - K eps (|c|^2 + r^2), evaluated in
-    // double (long double for fp64) and rounded DOWN, so the device-side test can only err towards
-    // "candidate".  The filter's error bound assumes finite, not absurdly scaled magnitudes; scenes
-    // outside that range use the exact scan.
-    std::vector<SphereHot<F>> &hfil = out.filter;
+    // Conservative scan filter table {c, thr} — in float for every F: thr = |c|^2 - r^2 - K eps32 (|c|^2 + r^2),
+    // evaluated in long double from the F-precision centre and radius and rounded DOWN, so the device-side
+    // test can only err towards "candidate" (K = kFilterK for fp32 rays; kFilterK64 for fp64 rays, whose
+    // components the filter rounds to float).  The bound assumes finite, not absurdly scaled magnitudes;
+    // scenes outside that range use the exact scan.
+    std::vector<SphereHot<float>> &hfil = out.filter;
     hfil.clear(), hfil.resize(n_pad > 0 ? n_pad : 1);
     bool &filter_ok = out.filter_ok;
     filter_ok = true;
     {
-        const long double eps = sizeof(F) == 4 ? 0x1p-24L : 0x1p-53L;
-        const long double big = sizeof(F) == 4 ? 1e30L : 1e280L, tiny = sizeof(F) == 4 ? 1e-25L : 1e-250L;
+        const long double eps = 0x1p-24L, K = sizeof(F) == 4 ? (long double)kFilterK : (long double)kFilterK64;
+        const long double big = 1e30L, tiny = 1e-25L;
         for (int i = 0; i < n_pad; ++i) {
-            hfil[i].cx = hhot[i].cx, hfil[i].cy = hhot[i].cy, hfil[i].cz = hhot[i].cz;
+            hfil[i].cx = (float)hhot[i].cx, hfil[i].cy = (float)hhot[i].cy, hfil[i].cz = (float)hhot[i].cz;
             if (i >= s->num_spheres) {
-                hfil[i].r2 = std::numeric_limits<F>::infinity(); // finite test values are always below it
+                hfil[i].r2 = std::numeric_limits<float>::infinity(); // finite test values are always below it
                 continue;
             }
             const long double cx = hhot[i].cx, cy = hhot[i].cy, cz = hhot[i].cz, r2 = hhot[i].r2;
             const long double c2 = cx * cx + cy * cy + cz * cz;
             if (!(std::isfinite((double)c2) && std::isfinite((double)r2)) || !(c2 + r2 <= big) || !(c2 + r2 >= tiny)) filter_ok = false;
-            const long double thr = (c2 - r2) - (long double)kFilterK * eps * (c2 + r2);
-            F t = (F)thr;
-            if ((long double)t > thr) t = std::nextafter(t, -std::numeric_limits<F>::infinity());
-            t = std::nextafter(t, -std::numeric_limits<F>::infinity()); // one more ulp of slack
+            const long double thr = (c2 - r2) - K * eps * (c2 + r2);
+            float t = (float)thr;
+            if ((long double)t > thr) t = std::nextafter(t, -std::numeric_limits<float>::infinity());
+            t = std::nextafter(t, -std::numeric_limits<float>::infinity()); // one more ulp of slack
             hfil[i].r2 = t;
         }
     }

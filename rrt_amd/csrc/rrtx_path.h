@@ -82,7 +82,6 @@ template <> struct SphereUnroll<double> {
 template <typename F> struct Limits;
 template <> struct Limits<float> {
     static RRTX_DEV float inf() { return __builtin_huge_valf(); }
-    static RRTX_DEV float margin() { return (float)kFilterK * 0x1p-24f; } // K * unit roundoff
     static RRTX_DEV float big() { return 1e30f; }
     static RRTX_DEV float tiny() { return 1e-30f; }
     static RRTX_DEV float coop_big() { return 1e15f; }   // squares and products of these stay finite
@@ -90,7 +89,6 @@ template <> struct Limits<float> {
 };
 template <> struct Limits<double> {
     static RRTX_DEV double inf() { return __builtin_huge_val(); }
-    static RRTX_DEV double margin() { return (double)kFilterK * 0x1p-53; }
     static RRTX_DEV double big() { return 1e280; }
     static RRTX_DEV double tiny() { return 1e-280; }
     static RRTX_DEV double coop_big() { return 1e120; }
@@ -562,28 +560,47 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
 // per sphere the host stores c and thr = |c|^2 - r^2 - K eps (|c|^2 + r^2) rounded down, and
 //   candidate  <=>  not (u^2 + b.c + g < thr).
 // Rays with non-finite or extreme components get g = +inf: everything is a candidate, the exact test decides.
-template <typename F> struct FilterRay {
-    F nx, ny, nz, bx, by, bz, g;
+// The filter runs in fp32 whatever F is: an fp64 ray is rounded to float first (kFilterK64 covers that).
+struct FilterRay {
+    float nx, ny, nz, bx, by, bz, g;
 };
-template <typename F> RRTX_DEV FilterRay<F> make_filter_ray(const Path<F> &path, F a)
+RRTX_DEV FilterRay make_filter_ray(const Path<float> &path, float a)
 {
-    FilterRay<F> r = {0, 0, 0, 0, 0, 0, Limits<F>::inf()};
-    const F o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
-    if (a >= Limits<F>::tiny() && a <= Limits<F>::big() && o2 <= Limits<F>::big()) {
-        const F inv = (F)1 / fsqrt(a);
+    FilterRay r = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
+    const float o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
+    if (a >= Limits<float>::tiny() && a <= Limits<float>::big() && o2 <= Limits<float>::big()) {
+        const float inv = 1.0f / fsqrt(a);
         r.nx = path.d.x * inv, r.ny = path.d.y * inv, r.nz = path.d.z * inv;
-        const F sdot = ffma(path.o.z, r.nz, ffma(path.o.y, r.ny, path.o.x * r.nx));
-        r.bx = (F)2 * ffma(-sdot, r.nx, path.o.x);
-        r.by = (F)2 * ffma(-sdot, r.ny, path.o.y);
-        r.bz = (F)2 * ffma(-sdot, r.nz, path.o.z);
-        r.g = ffma(Limits<F>::margin(), o2, ffma(sdot, sdot, -o2));
+        const float sdot = ffma(path.o.z, r.nz, ffma(path.o.y, r.ny, path.o.x * r.nx));
+        r.bx = 2.0f * ffma(-sdot, r.nx, path.o.x);
+        r.by = 2.0f * ffma(-sdot, r.ny, path.o.y);
+        r.bz = 2.0f * ffma(-sdot, r.nz, path.o.z);
+        r.g = ffma((float)kFilterK * 0x1p-24f, o2, ffma(sdot, sdot, -o2)); // K * unit roundoff
     }
     return r;
 }
-template <typename F> RRTX_DEV F filter_value(const FilterRay<F> &r, F cx, F cy, F cz)
+RRTX_DEV FilterRay make_filter_ray(const Path<double> &path, double a)
 {
-    const F uu = ffma(cz, r.nz, ffma(cy, r.ny, cx * r.nx));
-    const F w = ffma(r.bz, cz, ffma(r.by, cy, ffma(r.bx, cx, r.g)));
+    FilterRay r = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
+    // (decided in double: a value that overflows float must not become a finite-looking float)
+    const double o2d = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
+    if (a >= (double)Limits<float>::tiny() && a <= (double)Limits<float>::big() && o2d <= (double)Limits<float>::big()) {
+        const float ox = (float)path.o.x, oy = (float)path.o.y, oz = (float)path.o.z, dx = (float)path.d.x, dy = (float)path.d.y, dz = (float)path.d.z;
+        const float o2 = ffma(oz, oz, ffma(oy, oy, ox * ox));
+        const float inv = 1.0f / fsqrt(ffma(dz, dz, ffma(dy, dy, dx * dx)));
+        r.nx = dx * inv, r.ny = dy * inv, r.nz = dz * inv;
+        const float sdot = ffma(oz, r.nz, ffma(oy, r.ny, ox * r.nx));
+        r.bx = 2.0f * ffma(-sdot, r.nx, ox);
+        r.by = 2.0f * ffma(-sdot, r.ny, oy);
+        r.bz = 2.0f * ffma(-sdot, r.nz, oz);
+        r.g = ffma((float)kFilterK64 * 0x1p-24f, o2, ffma(sdot, sdot, -o2));
+    }
+    return r;
+}
+RRTX_DEV float filter_value(const FilterRay &r, float cx, float cy, float cz)
+{
+    const float uu = ffma(cz, r.nz, ffma(cy, r.ny, cx * r.nx));
+    const float w = ffma(r.bz, cz, ffma(r.by, cy, ffma(r.bx, cx, r.g)));
     return ffma(uu, uu, w);
 }
 
