@@ -46,13 +46,6 @@ namespace rrtx {
 #define RRTX_LDS_BLOCK 4 // records per LDS-sourced block: 16 VGPRs of operands keep the kernel at 6 waves/SIMD
 #endif
 
-#ifdef RRTX_EXPERIMENT // timing experiments only (wrong images): 1 = compare only, 2 = compare + branch, no push
-#if RRTX_EXPERIMENT == 1
-#define RRTX_PUSH_ASM(CMP, THRC) asm volatile(CMP " vcc, %[thr], %[val]" : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save) : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U) : "vcc", "scc", "memory")
-#else
-#define RRTX_PUSH_ASM(CMP, THRC) asm volatile(CMP " vcc, %[thr], %[val]\n\ts_cbranch_vccz 1f\n\ts_nop 0\n1:" : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save) : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U) : "vcc", "scc", "memory")
-#endif
-#else
 #define RRTX_PUSH_ASM(CMP, THRC)                                                                                       \
     asm volatile(CMP " vcc, %[thr], %[val]\n\t"                                                                        \
                      "s_cbranch_vccz 1f\n\t"                                                                           \
@@ -67,7 +60,6 @@ namespace rrtx {
                  : [cnt] "+v"(cnt), [addr] "=&v"(addr), [tmp] "=&v"(tmp), [save] "=&s"(save)                            \
                  : [thr] THRC(thr), [val] "v"(value), [base] "v"(lane_lds_addr), [k0] "s"(k0), [u] "n"(U)               \
                  : "vcc", "scc", "memory")
-#endif
 
 // lane_lds_addr = LDS byte address of this lane's slot 0; slot s is 256 bytes further (64 lanes x 4 B).
 // THR_IN_VGPR: the threshold came from LDS (vector register) instead of a scalar load.
@@ -231,18 +223,13 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         // that need no task: a wave that is slow (the youngest waves
         // of a SIMD get the fewest issue slots) or holds long tasks would otherwise work through its
         // pool long after everyone else has left.
-#ifndef RRTX_POLL_MASK
-#define RRTX_POLL_MASK 3u
-#endif
-#ifndef RRTX_EXP_NOPOLL
-        if (!queue_over && (loop_count & RRTX_POLL_MASK) == 0u) {
+        if (!queue_over && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %)
             // (a flag on a line of its own: reading the cursor itself, which every pull hits with an
             // atomic, costs ~30 us a poll)
             uint32_t over = 0;
             if (lane == 0) over = __hip_atomic_load(P.queue + kQueueOverFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             queue_over = __builtin_amdgcn_readfirstlane(over) != 0u;
         }
-#endif
         loop_count += 1;
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
         uint64_t want = __ballot(need_task);
@@ -252,10 +239,6 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                 // guided batches: half of an even share of what is left of the region (chunk tasks, then
                 // single-sample tasks), so that the pools waves are left with shrink towards its end
                 uint32_t batch;
-#ifdef RRTX_EXP_NOGUIDED
-                batch = cursor_seen < P.taper_task_base ? kTaskBatch : kTaperBatch;
-                if (false) {}
-#else
                 if (cursor_seen < P.taper_task_base) {
                     batch = (P.taper_task_base - cursor_seen) / (2u * n_waves);
                     batch = batch < kTaskBatchMin ? kTaskBatchMin : (batch > kTaskBatch ? kTaskBatch : batch);
@@ -264,7 +247,6 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                     batch = (P.total_tasks > cursor_seen ? P.total_tasks - cursor_seen : 0u) / (2u * n_waves);
                     batch = batch < kTaskBatch ? kTaskBatch : (batch > kTaperBatch ? kTaperBatch : batch);
                 }
-#endif
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(P.queue, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
