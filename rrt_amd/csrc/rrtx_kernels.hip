@@ -223,7 +223,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         // that need no task: a wave that is slow (the youngest waves
         // of a SIMD get the fewest issue slots) or holds long tasks would otherwise work through its
         // pool long after everyone else has left.
-        if (!queue_over && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %)
+        if (!queue_over && P.handoff_lanes > 0 && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %; nobody hands off without a tail kernel)
             // (a flag on a line of its own: reading the cursor itself, which every pull hits with an
             // atomic, costs ~30 us a poll)
             uint32_t over = 0;
