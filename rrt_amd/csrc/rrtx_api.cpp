@@ -441,7 +441,7 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         c->d_tail_units = nullptr;
     }
     c->tail_capacity = 0;
-    if (c->tail_ok && !c->accel && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) { // (an accelerated segment is cheap enough for waves to finish their own paths)
+    if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
         const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
         c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
         c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
@@ -486,13 +486,13 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     if (c->p.fp64) {
         KernelParams<double> P = make_params<double>(c, out);
         RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(c->accel ? launch_resume<double>(P, c->use_filter, c->grid_blocks, st) : launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
         if (c->use_partial) RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, shape, st));
     }
     else {
         KernelParams<float> P = make_params<float>(c, out);
         RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
+        if (c->tail_capacity) RRTX_HIP(c->accel ? launch_resume<float>(P, c->use_filter, c->grid_blocks, st) : launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
         if (c->use_partial) RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, shape, st));
     }
     RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));

@@ -110,6 +110,39 @@ template <typename F> RRTX_DEV const RRTX_CONST_AS KernelParams<F> *cold_params(
     return p;
 }
 
+// Work units of a parked item (written by the render kernel, P.tail_units = item << 3 | k): unit 0
+// continues the item's partial sum over all but the last kTailSplit - 1 remaining samples of its task,
+// units k >= 1 are those last samples one by one; the result of unit k goes to tail_rad[item][k] and
+// tail_sum_kernel adds them in sample order.
+template <typename F>
+RRTX_DEV void load_unit(const KernelParams<F> &P, uint32_t u, uint32_t &task, int &s_cur, int &s_end, bool &need_ray, bool &single, uint32_t &out_index, V3<F> &acc, Path<F> &path, Rng &rng)
+{
+    const uint32_t item = u >> 3, k = u & 7u;
+    const TailItem<F> it = P.tail_items[item];
+    task = it.task;
+    int px_i, px_j, s_first, s_task_end;
+    task_decode<F>(P, task, px_i, px_j, s_first, s_task_end);
+    const int remaining = s_task_end - it.s_cur;
+    const int n0 = remaining > kTailSplit - 1 ? remaining - (kTailSplit - 1) : 1;
+    if (k == 0) {
+        s_cur = it.s_cur, s_end = it.s_cur + n0;
+        need_ray = it.need_ray != 0;
+        acc = mk<F>(it.acc[0], it.acc[1], it.acc[2]);
+        path.o = mk<F>(it.o[0], it.o[1], it.o[2]);
+        path.d = mk<F>(it.d[0], it.d[1], it.d[2]);
+        path.tm = it.tm;
+        path.atten = mk<F>(it.atten[0], it.atten[1], it.atten[2]);
+        path.depth = it.depth;
+        rng.k0 = it.k0, rng.k1 = it.k1, rng.n = it.n;
+    }
+    else {
+        s_cur = it.s_cur + n0 + (int)k - 1, s_end = s_cur + 1;
+        need_ray = true;
+    }
+    single = k != 0;
+    out_index = item * (uint32_t)kTailSplit + k;
+}
+
 // Records the scan reads: the fp32 filter table, or (FILTER = false) the exact-test table in F.
 template <typename F, bool FILTER> struct ScanType {
     typedef F type;
@@ -138,7 +171,10 @@ template <typename F> struct ScanType<F, true> {
 // ACCEL: 0 = every segment is scanned; 1 / 2 = accelerated closest hit (accel_closest_hit) with the grid
 // and the exact-test records read from HBM / from a copy in LDS, the scan being the fallback for the
 // rays the grid is not proven for.
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
+// RESUME: a second pass of the accelerated variants over the work units the first pass parked when the
+// queue ran out (lanes take up paths where they were left, densely packed again); results go to
+// tail_rad, nothing is parked again: an accelerated iteration is cheap enough to run paths to their end.
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -195,6 +231,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
     path.tm = 0;
     path.depth = 0;
     Rng rng = {0, 0, 0};
+    uint32_t out_index = 0; // RESUME: where the unit's result goes in tail_rad
+    bool single = false;    // RESUME: the result is the sample itself (units k >= 1), not a running sum
+    const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t plist_count = 0xFFFFu; // header of the current pixel's camera-ray list
     // ACCEL: a grid walk in progress (see accel_closest_hit)
@@ -223,7 +262,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         // that need no task: a wave that is slow (the youngest waves
         // of a SIMD get the fewest issue slots) or holds long tasks would otherwise work through its
         // pool long after everyone else has left.
-        if (!queue_over && P.handoff_lanes > 0 && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %; nobody hands off without a tail kernel)
+        if (!RESUME && !queue_over && P.handoff_lanes > 0 && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %; nobody hands off without a tail kernel)
             // (a flag on a line of its own: reading the cursor itself, which every pull hits with an
             // atomic, costs ~30 us a poll)
             uint32_t over = 0;
@@ -234,7 +273,19 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
         uint64_t want = __ballot(need_task);
         while (want != 0ull) {
-            if (pool_next == pool_end) {
+            if (RESUME && pool_next == pool_end) {
+                if (queue_dry) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.tail_count + 1, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n_units_in) {
+                    queue_dry = queue_over = true;
+                    break;
+                }
+                pool_next = base;
+                pool_end = n_units_in - base < 64u ? n_units_in : base + 64u;
+            }
+            if (!RESUME && pool_next == pool_end) {
                 if (queue_dry) break;
                 // guided batches: half of an even share of what is left of the region (chunk tasks, then
                 // single-sample tasks), so that the pools waves are left with shrink towards its end
@@ -265,14 +316,18 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             const uint32_t avail = pool_end - pool_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u)); // set bits below this lane
             if (need_task && rank < avail) {
-                task = pool_next + rank;
                 need_task = false;
-                {
+                if (RESUME) {
+                    load_unit<F>(P, P.tail_units[pool_next + rank], task, s_cur, s_end, need_ray, single, out_index, acc, path, rng);
+                    plist_count = 0xFFFFu; // a path in flight has no camera-ray list (a fresh camera ray fetches its own)
+                }
+                else {
+                    task = pool_next + rank;
                     int pi, pj;
                     task_decode<F>(*cold_params<F>(), task, pi, pj, s_cur, s_end);
+                    acc = mk<F>(0, 0, 0);
+                    need_ray = true;
                 }
-                acc = mk<F>(0, 0, 0);
-                need_ray = true;
             }
             const uint32_t wanted = (uint32_t)__popcll(want);
             pool_next += wanted < avail ? wanted : avail;
@@ -290,11 +345,12 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             // 0.36 % of paths that bounce 50 times), and a lone wave needs ~10 us per segment of the
             // lane-per-ray scan: that tail cost ~6 ms per launch whatever the frame size.  Below
             // `handoff_lanes` live lanes the wave parks its unfinished work items (pixel, sample, ray,
-            // attenuation, RNG position, partial sum) in HBM and exits; tail_kernel finishes them.
+            // attenuation, RNG position, partial sum) in HBM and exits; tail_kernel finishes them (the
+            // accelerated variants: a RESUME pass of this kernel).
             // ... or after `handoff_iters` more iterations, whatever is still alive — and whatever tasks
             // are left in its pool: the launch then ends a bounded time after the queue does.
             if (queue_over) dry_iters += 1;
-            if (queue_over && P.handoff_lanes > 0 && pool_end - pool_next <= 64u && ((int)__popcll(live) <= P.handoff_lanes || dry_iters > P.handoff_iters)) {
+            if (!RESUME && queue_over && P.handoff_lanes > 0 && pool_end - pool_next <= 64u && ((int)__popcll(live) <= P.handoff_lanes || dry_iters > P.handoff_iters)) {
                 // (every lane still executes here; lane 0 speaks for the wave)
                 auto park = [&](bool active, const TailItem<F> &it, int units) {
                     const uint64_t who = __ballot(active);
@@ -322,6 +378,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
                         ubase += (uint32_t)__popcll(has[k]);
                     }
                 };
+                if (ACCEL != 0 && alive && in_walk) n_segments -= 1; // parked in mid-walk: the resume pass walks (and counts) this segment from its start
                 TailItem<F> it;
                 it.task = task, it.s_cur = s_cur, it.depth = path.depth, it.need_ray = need_ray ? 1u : 0u;
                 it.k0 = rng.k0, it.k1 = rng.k1, it.n = rng.n, it.pad = 0;
@@ -600,10 +657,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
             } // max_depth > 0
 
             if (done) {
-                acc = vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
+                acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
                 s_cur += 1;
                 if (s_cur == s_end) {
-                    F *o = task_slot<F>(*cold_params<F>(), task);
+                    F *o = RESUME ? P.tail_rad + (size_t)out_index * 3 : task_slot<F>(*cold_params<F>(), task);
                     o[0] = acc.x;
                     o[1] = acc.y;
                     o[2] = acc.z;
@@ -621,7 +678,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> __global
         atomicAdd(&P.counters[3], (unsigned long long)n_scanned);
     }
 #ifdef RRTX_DIAG
-    if (lane == 0) {
+    if (lane == 0 && !RESUME) {
         const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
         unsigned long long *d = P.diag + (size_t)wid * 8;
         d[0] = diag_t0, d[1] = diag_dry, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = diag_iters, d[4] = diag_iters_dry;
@@ -722,32 +779,7 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
             const uint32_t avail = pool_end - pool_next;
             const uint32_t rank = (uint32_t)__popcll(want & lanes_below_group) / (uint32_t)G; // needy groups before mine
             if (need && rank < avail) {
-                const uint32_t u = P.tail_units[pool_next + rank];
-                const uint32_t item = u >> 3, k = u & 7u;
-                const TailItem<F> it = P.tail_items[item];
-                task = it.task;
-                int px_i, px_j, s_first, s_task_end;
-                task_decode<F>(P, task, px_i, px_j, s_first, s_task_end);
-                // unit 0: the item's samples but the last kTailSplit - 1; unit k: the k-th of those
-                const int remaining = s_task_end - it.s_cur;
-                const int n0 = remaining > kTailSplit - 1 ? remaining - (kTailSplit - 1) : 1;
-                if (k == 0) {
-                    s_cur = it.s_cur, s_end = it.s_cur + n0;
-                    need_ray = it.need_ray != 0;
-                    acc = mk<F>(it.acc[0], it.acc[1], it.acc[2]);
-                    path.o = mk<F>(it.o[0], it.o[1], it.o[2]);
-                    path.d = mk<F>(it.d[0], it.d[1], it.d[2]);
-                    path.tm = it.tm;
-                    path.atten = mk<F>(it.atten[0], it.atten[1], it.atten[2]);
-                    path.depth = it.depth;
-                    rng.k0 = it.k0, rng.k1 = it.k1, rng.n = it.n;
-                }
-                else {
-                    s_cur = it.s_cur + n0 + (int)k - 1, s_end = s_cur + 1;
-                    need_ray = true;
-                }
-                single = k != 0;
-                out_index = item * (uint32_t)kTailSplit + k;
+                load_unit<F>(P, P.tail_units[pool_next + rank], task, s_cur, s_end, need_ray, single, out_index, acc, path, rng);
                 have = true;
                 need = false;
             }
@@ -1049,6 +1081,26 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
 #ifndef RRTX_TAIL_GROUP
 #define RRTX_TAIL_GROUP 8 // lanes per ray in the tail kernel (measured on final.txt spp 48: 32 -> 1.82, 16 -> 1.33, 8 -> 1.18, 4 -> 1.17 ms)
 #endif
+// the accelerated variants finish their parked work with a resume pass of themselves (lane per ray on
+// the grid), then tail_sum_kernel; `grid_blocks` is the render grid
+template <typename F> hipError_t launch_resume(const KernelParams<F> &P, bool filter, int grid_blocks, hipStream_t stream)
+{
+    const size_t alds = accel_lds_bytes<F>(P);
+    if (!filter) {
+        if (alds)
+            hipLaunchKernelGGL((render_kernel<F, false, 0, false, 2, true>), dim3(grid_blocks), dim3(kBlockThreads), alds, stream, P);
+        else
+            hipLaunchKernelGGL((render_kernel<F, false, 0, false, 1, true>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    }
+    else if (alds)
+        hipLaunchKernelGGL((render_kernel<F, true, 0, false, 2, true>), dim3(grid_blocks), dim3(kBlockThreads), alds, stream, P);
+    else
+        hipLaunchKernelGGL((render_kernel<F, true, 0, false, 1, true>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tail_sum_kernel<F>, dim3(256), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
 template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filter, int grid_blocks, hipStream_t stream)
 {
     const size_t lds = (size_t)P.n_sph_padded * (filter ? sizeof(SphereHot<float>) + sizeof(SphereHot<F>) : sizeof(SphereHot<F>));
@@ -1098,6 +1150,8 @@ template hipError_t launch_render<double>(const KernelParams<double> &, bool, in
 template hipError_t launch_primary_lists<float>(const KernelParams<float> &, uint16_t *, hipStream_t);
 template hipError_t launch_primary_lists<double>(const KernelParams<double> &, uint16_t *, hipStream_t);
 template hipError_t launch_tail<float>(const KernelParams<float> &, bool, int, hipStream_t);
+template hipError_t launch_resume<float>(const KernelParams<float> &, bool, int, hipStream_t);
+template hipError_t launch_resume<double>(const KernelParams<double> &, bool, int, hipStream_t);
 template hipError_t launch_tail<double>(const KernelParams<double> &, bool, int, hipStream_t);
 template hipError_t launch_finalize<float>(const float *, float *, const FinalizeShape &, hipStream_t);
 template hipError_t launch_finalize<double>(const double *, double *, const FinalizeShape &, hipStream_t);

@@ -486,6 +486,11 @@ def test_accelerated_closest_hit_is_bit_identical(gpu, fp64):
     fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, flags=32)
     assert np.array_equal(fb, want)
     assert st["list_mismatches"] == 0
+    # without the resume pass (flag 8: waves finish their own paths), and with every wave parking early
+    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, flags=8)
+    assert np.array_equal(fb, want) and st["segments"] == stats["segments"]
+    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, handoff_lanes=64, handoff_iters=1)
+    assert np.array_equal(fb, want) and st["segments"] == stats["segments"]
     # sharded and with whole-pixel tasks
     fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=fp64, use_bvh=True, sample_chunk=-1)
     assert np.array_equal(fb, Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)[0])
