@@ -80,6 +80,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
     double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
     if (!(cell > 0) || !std::isfinite(cell)) return false;
 
+    const double large = getenv("RRTX_GRID_LARGE") ? atof(getenv("RRTX_GRID_LARGE")) : 1.6;
     const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
     const double cam_o[3] = {(double)cam.origin[0], (double)cam.origin[1], (double)cam.origin[2]};
     std::vector<double> delta(boxes.size(), 0.0); // per primitive: how far its box is inflated
@@ -88,7 +89,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         size_t n_sized = 0;
         for (size_t i = 0; i < boxes.size(); ++i)
-            if (!(ext[i] > 1.6 * cell || boxes[i].r < cell / 50)) {
+            if (!(ext[i] > large * cell || boxes[i].r < cell / 50)) {
                 n_sized += 1;
                 for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k]), hi[k] = std::max(hi[k], boxes[i].hi[k]);
             }
@@ -112,7 +113,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             for (size_t i = 0; i < boxes.size(); ++i) {
                 const double r = boxes[i].r, m = 32 * eps * (R * R + r * r);
                 delta[i] = std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
-                if (ext[i] > 1.6 * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell)
+                if (ext[i] > large * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell)
                     always.push_back((uint32_t)boxes[i].idx);
                 else
                     infl.push_back(delta[i]);

@@ -162,6 +162,9 @@ template <typename F> struct ScanType<F, true> {
 #ifndef RRTX_ACCEL_WAVES_F64
 #define RRTX_ACCEL_WAVES_F64 4 // ... and the fp64 ones (127 VGPRs: 66.9 vs 72.5 ms at spp 504; the fp64 list scan takes 128.2)
 #endif
+#ifndef RRTX_ACCEL_POLL_MASK
+#define RRTX_ACCEL_POLL_MASK 3u
+#endif
 #ifndef RRTX_WALK_SLICE
 #define RRTX_WALK_SLICE 4 // cells a lane walks per iteration of the render loop (0: to the end); 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms
 #endif
@@ -262,7 +265,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // that need no task: a wave that is slow (the youngest waves
         // of a SIMD get the fewest issue slots) or holds long tasks would otherwise work through its
         // pool long after everyone else has left.
-        if (!RESUME && !queue_over && P.handoff_lanes > 0 && (loop_count & 3u) == 0u) { // (every 4th iteration: free; every iteration: 7 %; nobody hands off without a tail kernel)
+        if (!RESUME && !queue_over && P.handoff_lanes > 0 && (loop_count & (ACCEL != 0 ? RRTX_ACCEL_POLL_MASK : 3u)) == 0u) { // (every 4th iteration: free; every iteration: 7 %; nobody hands off without a tail kernel)
             // (a flag on a line of its own: reading the cursor itself, which every pull hits with an
             // atomic, costs ~30 us a poll)
             uint32_t over = 0;

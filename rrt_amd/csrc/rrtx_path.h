@@ -45,6 +45,22 @@ template <typename F> RRTX_DEV F vlen2(V3<F> a) { return a.x * a.x + a.y * a.y +
 
 RRTX_DEV float fsqrt(float x) { return __builtin_sqrtf(x); } // correctly rounded (hipcc default)
 RRTX_DEV double fsqrt(double x) { return __builtin_sqrt(x); }
+// Approximate (about 1 ulp) reciprocal, square root and reciprocal square root: ONE instruction each on
+// the device against ~10 for the IEEE forms.  For the geometry of the grid walk only (which cell comes
+// next, when to stop), where errors of a few ulps are covered a thousand times over by the inflation of the
+// cells' boxes and the walk's slack — never for path arithmetic, which must round like the reference's.
+#if defined(__HIP_DEVICE_COMPILE__)
+RRTX_DEV float approx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RRTX_DEV double approx_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+RRTX_DEV float approx_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RRTX_DEV double approx_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
+RRTX_DEV float approx_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+RRTX_DEV double approx_rsqrt(double x) { return __builtin_amdgcn_rsq(x); }
+#else
+template <typename F> RRTX_DEV F approx_rcp(F x) { return (F)1 / x; }
+template <typename F> RRTX_DEV F approx_sqrt(F x) { return fsqrt(x); }
+template <typename F> RRTX_DEV F approx_rsqrt(F x) { return (F)1 / fsqrt(x); }
+#endif
 RRTX_DEV float ffabs(float x) { return __builtin_fabsf(x); }
 RRTX_DEV double ffabs(double x) { return __builtin_fabs(x); }
 RRTX_DEV float ffmin(float a, float b) { return __builtin_fminf(a, b); }
@@ -469,7 +485,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     const F ox = path.o.x, oy = path.o.y, oz = path.o.z, dx = path.d.x, dy = path.d.y, dz = path.d.z;
     const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
     const F dist2 = rx * rx + ry * ry + rz * rz;
-    const F reach = P.grid.slack1 * (fsqrt(dist2) + P.grid.half_diag); // 1.5 sqrt(32 eps) (|o - centre| + half diagonal)
+    const F reach = P.grid.slack1 * (approx_sqrt(dist2) + P.grid.half_diag); // 1.5 sqrt(32 eps) (|o - centre| + half diagonal)
     const int tri_base_ = P.n_sph_padded + P.n_msph;
     PendingRoot<F> pend = {-1, 0, 0};
     const F o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
@@ -479,7 +495,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     // (a component too small for 1 / d to be finite counts as parallel: (x - o) * inf would be NaN for x == o)
     bool par[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) par[k] = !(ffabs(d[k]) >= Limits<F>::coop_tiny()), inv[k] = par[k] ? Limits<F>::inf() : (F)1 / d[k];
+    for (int k = 0; k < 3; ++k) par[k] = !(ffabs(d[k]) >= Limits<F>::coop_tiny()), inv[k] = par[k] ? Limits<F>::inf() : approx_rcp(d[k]);
     if (!resume) {
         {
             // the rays the unordered rule is proven for
@@ -515,7 +531,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
         }
         if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return kWalkDone; // (a hair of tolerance on the far side: the slab arithmetic rounds too)
         if (is_far) return kWalkNeedsScan;
-        if (t_in > best.t + (P.grid.slack + reach) / fsqrt(a)) return kWalkDone;
+        if (t_in > best.t + (P.grid.slack + reach) * approx_rsqrt(a)) return kWalkDone;
         // the cell of the entry point
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -526,7 +542,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     }
     else
         ci[0] = (int)(walk_cell & 1023u), ci[1] = (int)((walk_cell >> 10) & 1023u), ci[2] = (int)(walk_cell >> 20);
-    const F slack_t = (P.grid.slack + reach) / fsqrt(a);
+    const F slack_t = (P.grid.slack + reach) * approx_rsqrt(a);
     // the DDA's per-axis distances to the next cell boundary (from the cell, not accumulated: a resumed
     // walk must not depend on where it was interrupted)
 #pragma unroll
