@@ -222,7 +222,7 @@ def main():
                        "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests),
                        "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic() if world == 1 and args.spp == SPP else None,
-                         "kernel": "rrtx::render_kernel<float, true, 1>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
+                         "kernel": "rrtx::render_kernel<float, true, 1, false, 0, false>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
                          "note": "logical primitive-read roofline (SURVEY.md 8d): algorithmic bytes = what the reference's list scan reads (segments x 488 spheres x 16 B); a record read from the scalar cache or LDS serves all 64 rays of a wave and camera rays are resolved from per-pixel candidate lists (config.prim_tests_executed_per_launch), so frac > 1 is legitimate; binding unit: VALU issue (DESIGN.md 3)"},
         }
         if accel is not None:

@@ -19,8 +19,9 @@ namespace rrtx {
 //
 // Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2 x their median
 // extent; measured on final.txt: 1.5 / 2 / 2.5 / 3.5 -> 53.2 / 49.5 / 51.5 / 74 ms at spp 504); primitives
-// larger than 1.6 cells, spheres smaller than a fiftieth of a cell and all triangles go into the
-// "always" list.  Every gridded primitive is entered into all cells its box, INFLATED, overlaps.
+// larger than 1.6 cells (RRTX_GRID_LARGE; with the three r = 1 spheres of final.txt gridded the grid has
+// three layers of cells instead of one: 66.8 against 41.1 ms), spheres smaller than a fiftieth of a cell
+// and all triangles go into the "always" list.  Every gridded primitive is entered into all cells its box, INFLATED, overlaps.
 // By how much: the reference's discriminant, evaluated in floating point, can be >= 0 only if the
 // ray's line passes within sqrt(r^2 + m) of the centre, m = 32 eps (|o - c|^2 + r^2) (a bound on the
 // rounding error of (oc.d)^2 - |d|^2 (|oc|^2 - r^2) relative to |d|^2; 24 eps by the usual gamma_n

@@ -14,6 +14,6 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_
   timeout -k 10 200 rocprofv3 --output-format csv --pmc $grp -d $O/p$i -o p$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc$i.json 2> $O/pmc$i.err || tail -3 $O/pmc$i.err
 done
 cd $R
-for k in "render_kernel<float, true, 1, false, 0>" "render_kernel<float, true, 0, false, 2>" tail_kernel; do echo "== $k"; PMC_KERNEL="$k" python3 tools/pmc_summary.py $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 $O/p8; done > $O/pmc_summary.txt
+for k in "render_kernel<float, true, 1, false, 0, false>" "render_kernel<float, true, 0, false, 2, false>" "render_kernel<float, true, 0, false, 2, true>" tail_kernel; do echo "== $k"; PMC_KERNEL="$k" python3 tools/pmc_summary.py $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 $O/p8; done > $O/pmc_summary.txt
 cat $O/trace/*kernel_stats.csv | head -12
 cat $O/pmc_summary.txt
