@@ -13,7 +13,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBlocks = 31; // 488 spheres padded to 496
 
-template <int THREADS, bool GROUP> __global__ void __launch_bounds__(THREADS) k_mfma(const uint4 *btab, float *out, int segments, float seed)
+template <int THREADS, int GROUP> __global__ void __launch_bounds__(THREADS) k_mfma(const uint4 *btab, float *out, int segments, float seed)
 {
     __shared__ uint4 b_lds[kBlocks * 2 * 64]; // [block][u|w][lane]: 62 KB
     for (int i = threadIdx.x; i < kBlocks * 2 * 64; i += THREADS) b_lds[i] = btab[i];
@@ -37,6 +37,15 @@ template <int THREADS, bool GROUP> __global__ void __launch_bounds__(THREADS) k_
                 u[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(au[t], bu, zero, 0, 0, 0);
                 w[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[t], bw, zero, 0, 0, 0);
             }
+            if (GROUP == 16) { // one branch per block of 16 result registers
+                float f[16];
+                unsigned long long any = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) f[q] = __builtin_fmaf(u[q >> 2][q & 3], u[q >> 2][q & 3], w[q >> 2][q & 3]), any |= __ballot(!(f[q] < 0.0f));
+                if (__builtin_expect(any != 0ull, 0))
+                    for (int q = 0; q < 16; ++q) hits += !(f[q] < 0.0f) ? 1u : 0u;
+            }
+            else
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (GROUP) { // one branch per four result registers
@@ -147,13 +156,15 @@ int main()
     hipMemcpy(ds, hs.data(), hs.size() * sizeof(float4), hipMemcpyHostToDevice);
     const double clk = 2.4e9, pairs_per_wave = (double)segments * kBlocks * 16 * 64;
     {
-        double ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<1024, false>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
+        double ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<1024, 0>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
         printf("mfma bf16 filter, 4 waves/SIMD, branch per result register: %.3f ms  %.2f pairs/clk/SIMD\n", ms, pairs_per_wave * 4 / (ms * 1e-3 * clk));
-        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<1024, true>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<1024, 4>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
         printf("mfma bf16 filter, 4 waves/SIMD, branch per four registers:  %.3f ms  %.2f pairs/clk/SIMD\n", ms, pairs_per_wave * 4 / (ms * 1e-3 * clk));
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<1024, 16>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
+        printf("mfma bf16 filter, 4 waves/SIMD, branch per block (16 registers): %.3f ms  %.2f pairs/clk/SIMD\n", ms, pairs_per_wave * 4 / (ms * 1e-3 * clk));
         ms = time_ms([&] { hipLaunchKernelGGL((k_mfma_only<1024>), dim3(256), dim3(1024), 0, 0, db, dout, segments, 0.5f); });
         printf("the MFMAs and their LDS reads alone, 4 waves/SIMD:           %.3f ms  %.2f pairs/clk/SIMD\n", ms, pairs_per_wave * 4 / (ms * 1e-3 * clk));
-        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<512, true>), dim3(256), dim3(512), 0, 0, db, dout, segments, 0.5f); });
+        ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<512, 4>), dim3(256), dim3(512), 0, 0, db, dout, segments, 0.5f); });
         printf("mfma bf16 filter, 2 waves/SIMD, branch per four registers:  %.3f ms  %.2f pairs/clk/SIMD\n", ms, pairs_per_wave * 2 / (ms * 1e-3 * clk));
     }
     for (int wps : {4, 6}) {
