@@ -97,6 +97,18 @@ def measured_traffic():
     return None
 
 
+def measured_valu_issue():
+    """VALU issue utilisation of the headline kernel from the committed PMC summary (or None)."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_render_kernel.csv")
+    try:
+        for line in open(p):
+            if line.startswith("valu_issue_utilisation,"):
+                return float(line.split(",")[1])  # the first block of the file is the list-scan kernel
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +235,8 @@ def main():
                        "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic() if world == 1 and args.spp == SPP else None,
                          "kernel": "rrtx::render_kernel<float, true, 1, false, 0, false>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
+                         "valu_issue": {"filter_frac": round(float(scanned / world * 488) * 8 / 64 / (kernel_ms * 1e-3 * 1024 * 2.4e9 * 0.5), 4), "pmc_frac": measured_valu_issue() if world == 1 and args.spp == SPP else None,
+                                        "note": "the unit that binds: wave-instructions per clock per SIMD against the peak of 0.5 (256 CUs x 4 SIMDs at 2.4 GHz); filter_frac counts only the scan filter's 8 instructions per executed (ray, sphere) test of this run, pmc_frac is SQ_INSTS_VALU of the committed rocprofv3 pass (profiles/r01_pmc_render_kernel.csv)"},
                          "note": "logical primitive-read roofline (SURVEY.md 8d): algorithmic bytes = what the reference's list scan reads (segments x 488 spheres x 16 B); a record read from the scalar cache or LDS serves all 64 rays of a wave and camera rays are resolved from per-pixel candidate lists (config.prim_tests_executed_per_launch), so frac > 1 is legitimate; binding unit: VALU issue (DESIGN.md 3)"},
         }
         if accel is not None:
