@@ -161,7 +161,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         GridRec<F> G = {};
         CameraRec<F> camrec;
         memcpy(&camrec, c->cam_bytes, sizeof camrec);
-        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, s->num_triangles, camrec, cell_start, cell_prims, always, G)) {
+        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G)) {
             if (cell_prims.empty()) cell_prims.push_back(0);
             if (always.empty()) always.push_back(0), c->n_always = 0;
             else c->n_always = (int)always.size();
@@ -412,7 +412,8 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         (void)hipFree(c->d_plist);
         c->d_plist = nullptr;
     }
-    if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0) {
+    // (a LIST pass tests every moving sphere and triangle per camera ray: with a mesh in the grid the walk is the cheaper way)
+    if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && !(c->accel && c->n_tri + c->n_msph > 64)) {
         const size_t bytes = (size_t)c->local_rows * c->p.image_width * kPlistStride * sizeof(uint16_t);
         uint16_t *pl = nullptr;
         RRTX_HIP(hipMalloc((void **)&pl, bytes));

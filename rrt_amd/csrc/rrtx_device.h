@@ -106,6 +106,7 @@ template <typename F> struct GridRec {
                          // exact tests are too inaccurate for the inflation the cells were built with)
     F slack, slack1, half_diag; // the walk continues slack + slack1 (|o - center| + half_diag) world units beyond the closest hit so far
     int32_t max_steps;   // bound on the trips of the walk (cells stepped through + primitives tested)
+    F dir2_max;          // rays with |d|^2 above this take the list scan: the inflation of gridded triangles is proven up to it
 };
 
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,

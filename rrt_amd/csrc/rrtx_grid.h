@@ -36,24 +36,43 @@ namespace rrtx {
 // are tested against the grid's box blown up by their own sqrt(m) and, if they touch it, scanned.
 // The walk stops once the next cell begins more than slack0 + slack1 (|o - centre| + half diagonal)
 // beyond the closest hit, slack1 = 1.5 sqrt(32 eps): the along-ray error of a root.
+//
+// Triangles.  The reference's test (triangle.h:38-75) is Moeller-Trumbore with the
+// absolute cut |a| < 1e-7, a = e1 . (d x e2).  Its computed a, and the numerators of t, u, v, carry
+// rounding errors of at most 16 eps |d| |e1| |e2| resp. 16 eps |s| |e1| |e2|, |s| |d| |e2|, |s| |d| |e1|
+// (s = o - v0; cross product + dot product, gamma_n accounting with room to spare).  With
+// rho = 16 eps |d| |e1| |e2| / 1e-7 < 1 an accepted hit therefore has |a_exact| >= (1 - rho) 1e-7, and
+// inserting the computed (t, u, v) into o + t d = v0 + u e1 + v e2 leaves a residual of at most
+//     R = rho / (1 - rho) (3 |s| + t |d| + |e1| + |e2|):
+// the reported hit point lies within R of the triangle (u, v in [0, 1]).  A triangle is gridded - entered
+// in every cell its box, inflated by R + a hundredth of a cell, overlaps - if rho <= 1e-6 for every ray
+// the walk answers (|d|^2 <= dir2_max = 1e6, |s| and t |d| within far + the grid's half diagonal), the
+// inflation stays under half a cell and its box under `large` cells; everything else stays in the
+// always-list.  In fp64 rho ~ 2e-8 |d| |e1| |e2|: meshes are gridded.  In fp32 rho ~ 10 |d| |e1| |e2|: the
+// bound admits nothing of practical size, and a mesh scene keeps the list scan.
 // ---------------------------------------------------------------------------------------------
+constexpr double kGridDir2Max = 1e6; // |d|^2 up to which gridded triangles are proven (camera rays of final.txt: ~ 1e2)
 template <typename F>
 inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<SphereCold<F>> &cold, int n_sph, int n_sph_pad, const std::vector<MovingSphereRec<F>> &ms,
-                       int n_msph, int n_tri, const CameraRec<F> &cam, std::vector<uint32_t> &cell_start, std::vector<uint16_t> &cell_prims, std::vector<uint32_t> &always,
-                       GridRec<F> &G)
+                       int n_msph, const std::vector<TriangleRec<F>> &tri, int n_tri, const CameraRec<F> &cam, std::vector<uint32_t> &cell_start, std::vector<uint16_t> &cell_prims,
+                       std::vector<uint32_t> &always, GridRec<F> &G)
 {
     const int msph_base = n_sph_pad, tri_base = n_sph_pad + n_msph;
+    const double eps0 = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
     if ((int64_t)tri_base + n_tri >= 65535) return false; // cell lists hold 16-bit primitive indices
     struct Box {
         double lo[3], hi[3], r;
         int idx;
+        bool is_tri;
+        double e1e2, e_sum, vmax; // triangles: |e1| |e2|, |e1| + |e2|, largest vertex coordinate
+        bool candidate;           // may be gridded at all (triangles: only where the bound holds)
     };
     std::vector<Box> boxes;
     for (int i = 0; i < n_sph; ++i) {
         Box b;
         const double cc[3] = {(double)hot[i].cx, (double)hot[i].cy, (double)hot[i].cz}, r = std::fabs((double)cold[i].radius);
         for (int k = 0; k < 3; ++k) b.lo[k] = cc[k] - r, b.hi[k] = cc[k] + r;
-        b.r = r, b.idx = i;
+        b.r = r, b.idx = i, b.is_tri = false, b.candidate = true;
         boxes.push_back(b);
     }
     for (int i = 0; i < n_msph; ++i) {
@@ -70,13 +89,31 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
                 b.lo[k] = std::min(b.lo[k], ck - r - pad), b.hi[k] = std::max(b.hi[k], ck + r + pad);
             }
         }
-        b.r = r, b.idx = msph_base + i;
+        b.r = r, b.idx = msph_base + i, b.is_tri = false, b.candidate = true;
         boxes.push_back(b);
     }
-    if (boxes.size() < 32) return false; // nothing to gain on a handful of primitives
-    std::vector<double> ext;
-    for (const Box &b : boxes) ext.push_back(std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}));
-    std::vector<double> sorted = ext;
+    for (int i = 0; i < n_tri; ++i) {
+        // the vertices the device test sees: v0, v0 + e1, v0 + e2 with the stored (rounded) edges
+        Box b;
+        double l1 = 0, l2 = 0;
+        b.vmax = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double a0 = (double)tri[i].v0[k], a1 = a0 + (double)tri[i].e1[k], a2 = a0 + (double)tri[i].e2[k];
+            b.lo[k] = std::min({a0, a1, a2}), b.hi[k] = std::max({a0, a1, a2});
+            l1 += (double)tri[i].e1[k] * (double)tri[i].e1[k], l2 += (double)tri[i].e2[k] * (double)tri[i].e2[k];
+            b.vmax = std::max({b.vmax, std::fabs(a0), std::fabs(a1), std::fabs(a2)});
+        }
+        b.e1e2 = std::sqrt(l1) * std::sqrt(l2), b.e_sum = std::sqrt(l1) + std::sqrt(l2);
+        b.r = 1e300, b.idx = tri_base + i, b.is_tri = true; // (r: never "tiny")
+        b.candidate = 16 * eps0 * std::sqrt(kGridDir2Max) * b.e1e2 / 1e-7 <= 1e-6; // rho, see above
+        boxes.push_back(b);
+    }
+    std::vector<double> ext, sorted;
+    for (const Box &b : boxes) {
+        ext.push_back(std::max({b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}));
+        if (b.candidate) sorted.push_back(ext.back());
+    }
+    if (sorted.size() < 32) return false; // nothing to gain on a handful of primitives
     std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
     double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
     if (!(cell > 0) || !std::isfinite(cell)) return false;
@@ -90,7 +127,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         size_t n_sized = 0;
         for (size_t i = 0; i < boxes.size(); ++i)
-            if (!(ext[i] > large * cell || boxes[i].r < cell / 50)) {
+            if (boxes[i].candidate && !(ext[i] > large * cell || boxes[i].r < cell / 50)) {
                 n_sized += 1;
                 for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k]), hi[k] = std::max(hi[k], boxes[i].hi[k]);
             }
@@ -102,7 +139,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         // The grid answers rays that start within `far` of its centre: the larger, the fewer rays need the
         // fat-box test, but the more every box must be inflated.  Six half diagonals if that keeps the
         // inflation of a typical primitive under a tenth of a cell, else three; always past the camera.
-        double far = 0;
+        double far = 0, rho_max = 0;
         bool built = false;
         for (double mult : {6.0, 3.0}) {
             far = std::max(mult * hd, 1.25 * cam_dist);
@@ -111,15 +148,26 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             const double R = far + hd; // |o - c| of any ray the grid answers
             always.clear();
             std::vector<double> infl;
+            rho_max = 0;
             for (size_t i = 0; i < boxes.size(); ++i) {
-                const double r = boxes[i].r, m = 32 * eps * (R * R + r * r);
-                delta[i] = std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
-                if (ext[i] > large * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell)
-                    always.push_back((uint32_t)boxes[i].idx);
-                else
+                bool grid_it;
+                if (boxes[i].is_tri) {
+                    const double rho = 16 * eps * std::sqrt(kGridDir2Max) * boxes[i].e1e2 / 1e-7;
+                    const double resid = rho < 0.5 ? rho / (1 - rho) * (4 * R + boxes[i].e_sum) : 1e300;
+                    delta[i] = resid + 4 * eps * boxes[i].vmax + 0.01 * cell;
+                    grid_it = boxes[i].candidate && !(ext[i] > large * cell) && !(delta[i] > 0.5 * cell) && std::isfinite(delta[i]);
+                    if (grid_it) rho_max = std::max(rho_max, rho);
+                }
+                else {
+                    const double r = boxes[i].r, m = 32 * eps * (R * R + r * r);
+                    delta[i] = std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
+                    grid_it = !(ext[i] > large * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell);
+                }
+                if (grid_it)
                     infl.push_back(delta[i]);
+                else
+                    always.push_back((uint32_t)boxes[i].idx);
             }
-            for (int i = 0; i < n_tri; ++i) always.push_back((uint32_t)(tri_base + i));
             if (always.size() > 48 || infl.size() < 32) continue;
             std::nth_element(infl.begin(), infl.begin() + infl.size() / 2, infl.end());
             if (mult > 3.0 && infl[infl.size() / 2] > 0.1 * cell) continue;
@@ -195,7 +243,8 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         }
         G.far2 = (F)(far * far);
         G.slack = (F)(0.01 * cell);              // slack0
-        G.slack1 = (F)(1.5 * std::sqrt(32 * eps)); // times (|o - centre| + half diagonal)
+        G.slack1 = (F)std::max(1.5 * std::sqrt(32 * eps), 8 * rho_max); // times (|o - centre| + half diagonal); 8 rho: a gridded triangle's residual
+        G.dir2_max = (F)(rho_max > 0 ? kGridDir2Max : (sizeof(F) == 4 ? 1e15 : 1e120)); // (Limits<F>::coop_big() when no triangle is gridded)
         G.half_diag = (F)hd;
         G.max_steps = dims[0] + dims[1] + dims[2] + 3 + (int)cell_prims.size(); // trips of the walk: a cell step or a primitive test each
         if (getenv("RRTX_DEBUG_GRID"))

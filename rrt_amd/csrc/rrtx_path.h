@@ -500,7 +500,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
         {
             // the rays the unordered rule is proven for
             const F o2 = ox * ox + oy * oy + oz * oz;
-            const bool ok = a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
+            const bool ok = a >= Limits<F>::coop_tiny() && a <= P.grid.dir2_max && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
             if (!ok) return kWalkNeedsScan;
         }
 #ifdef RRTX_CONST_AS

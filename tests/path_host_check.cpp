@@ -75,6 +75,36 @@ template <typename F> static bool make_scene(Scene<F> &s, int variant, std::mt19
             s.tri.push_back(t);
         }
     }
+    if (variant == 2) {
+        // a triangle mesh: a UV sphere of radius 1.2 at (0.3, 1.2, -0.4), 24 x 48 quads,
+        // and a wavy sheet over a corner of the field
+        auto add_tri = [&](const double a[3], const double b[3], const double c[3]) {
+            TriangleRec<F> t = {};
+            for (int k = 0; k < 3; ++k) t.v0[k] = (F)a[k], t.e1[k] = (F)b[k] - (F)a[k], t.e2[k] = (F)c[k] - (F)a[k];
+            const F u1[3] = {t.e1[0], t.e1[1], t.e1[2]}, u2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+            t.n[0] = u1[1] * u2[2] - u1[2] * u2[1], t.n[1] = u1[2] * u2[0] - u1[0] * u2[2], t.n[2] = u1[0] * u2[1] - u1[1] * u2[0]; // (direction only: the walk does not use it)
+            s.tri.push_back(t);
+        };
+        const int NU = 24, NV = 48;
+        auto sph = [&](int i, int j, double out[3]) {
+            const double th = 3.14159265358979 * i / NU, ph = 6.28318530717959 * j / NV;
+            out[0] = 0.3 + 1.2 * std::sin(th) * std::cos(ph), out[1] = 1.2 + 1.2 * std::cos(th), out[2] = -0.4 + 1.2 * std::sin(th) * std::sin(ph);
+        };
+        for (int i = 0; i < NU; ++i)
+            for (int j = 0; j < NV; ++j) {
+                double p00[3], p01[3], p10[3], p11[3];
+                sph(i, j, p00), sph(i, j + 1, p01), sph(i + 1, j, p10), sph(i + 1, j + 1, p11);
+                if (i > 0) add_tri(p00, p10, p01);
+                if (i < NU - 1) add_tri(p01, p10, p11);
+            }
+        auto sheet = [&](int i, int j, double out[3]) { out[0] = 3 + 0.1 * i, out[2] = 2 + 0.1 * j, out[1] = 0.6 + 0.15 * std::sin(0.7 * i) * std::cos(0.5 * j); };
+        for (int i = 0; i < 30; ++i)
+            for (int j = 0; j < 30; ++j) {
+                double p00[3], p01[3], p10[3], p11[3];
+                sheet(i, j, p00), sheet(i, j + 1, p01), sheet(i + 1, j, p10), sheet(i + 1, j + 1, p11);
+                add_tri(p00, p01, p10), add_tri(p01, p11, p10);
+            }
+    }
     s.n_sph = (int)s.hot.size();
     s.n_pad = (s.n_sph + kSpherePad - 1) / kSpherePad * kSpherePad;
     while ((int)s.hot.size() < s.n_pad) { // never-hit padding, as the library packs it
@@ -87,9 +117,9 @@ template <typename F> static bool make_scene(Scene<F> &s, int variant, std::mt19
     s.cam.time0 = 0, s.cam.time1 = variant == 1 ? (F)1 : (F)0;
     if (s.ms.empty()) s.ms.resize(1);
     if (s.tri.empty()) s.tri.resize(1);
-    const int n_ms = variant == 1 ? 40 : 0, n_tri = variant == 1 ? 4 : 0;
+    const int n_ms = variant == 1 ? 40 : 0, n_tri = variant == 1 ? 4 : (variant == 2 ? (int)s.tri.size() : 0);
     GridRec<F> G = {};
-    if (!build_grid<F>(s.hot, s.cold, s.n_sph, s.n_pad, s.ms, n_ms, n_tri, s.cam, s.cell_start, s.cell_prims, s.always, G)) return false;
+    if (!build_grid<F>(s.hot, s.cold, s.n_sph, s.n_pad, s.ms, n_ms, s.tri, n_tri, s.cam, s.cell_start, s.cell_prims, s.always, G)) return false;
     if (s.cell_prims.empty()) s.cell_prims.push_back(0);
     KernelParams<F> &P = s.P;
     P.sph_hot = s.hot.data(), P.sph_cold = s.cold.data(), P.msph = s.ms.data(), P.tri = s.tri.data();
@@ -158,6 +188,15 @@ template <typename F> static int run(const char *name, int variant, long n_rays,
             o[0] = 30 * (U(gen) - 0.5), o[1] = 5 + 40 * U(gen), o[2] = 30 * (U(gen) - 0.5);
             d[1] = -std::fabs(d[1]) - 1;
         }
+        else if (kind == 7 && s.P.n_tri > 4 && (i & 8)) { // in the plane of a triangle, up to a perturbation of 1e-12 .. 1e-3: where Moeller-Trumbore is at its worst
+            const TriangleRec<F> &t = s.tri[(size_t)(U(gen) * s.P.n_tri) % (size_t)s.P.n_tri];
+            const double bu = 3 * U(gen) - 1, bv = 3 * U(gen) - 1, cu = 6 * (U(gen) - 0.5), cv = 6 * (U(gen) - 0.5), pert = std::pow(10.0, -12 + 9 * U(gen));
+            for (int k = 0; k < 3; ++k) {
+                const double target = (double)t.v0[k] + bu * (double)t.e1[k] + bv * (double)t.e2[k];
+                o[k] = (double)t.v0[k] + cu * 3 * (double)t.e1[k] + cv * 3 * (double)t.e2[k];
+                d[k] = target - o[k] + pert * N(gen);
+            }
+        }
         else { // anywhere near, any direction, any scale
             o[0] = 40 * (U(gen) - 0.5), o[1] = 3 * U(gen), o[2] = 40 * (U(gen) - 0.5);
             const double sc = std::pow(10.0, 4 * (U(gen) - 0.5));
@@ -208,5 +247,11 @@ int main(int argc, char **argv)
     bad |= run<float>("fp32", 1, n, 2);
     bad |= run<double>("fp64", 0, n / 2, 3);
     bad |= run<double>("fp64", 1, n / 2, 4);
+    bad |= run<double>("fp64", 2, n / 2, 5); // the mesh: gridded in fp64 ...
+    {
+        std::mt19937_64 gen(6);
+        Scene<float> s; // ... and not in fp32, where the bound admits no triangle of this size: no grid, the list is scanned
+        if (make_scene<float>(s, 2, gen)) std::printf("fp32 variant 2: a grid was built for a mesh the bound does not cover\n"), bad |= 1;
+    }
     return bad;
 }

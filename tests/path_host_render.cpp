@@ -41,7 +41,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
     bool grid = false;
     if (mode == 1) {
         GridRec<F> G = {};
-        grid = ps.tail_ok && build_grid<F>(ps.hot, ps.cold, desc.num_spheres, ps.n_pad, ps.ms, desc.num_moving_spheres, desc.num_triangles, ps.cam, cell_start, cell_prims, always, G);
+        grid = ps.tail_ok && build_grid<F>(ps.hot, ps.cold, desc.num_spheres, ps.n_pad, ps.ms, desc.num_moving_spheres, ps.tri, desc.num_triangles, ps.cam, cell_start, cell_prims, always, G);
         if (grid) {
             if (cell_prims.empty()) cell_prims.push_back(0);
             P.grid = G, P.grid_cell_start = cell_start.data(), P.grid_cell_prims = cell_prims.data(), P.grid_always = always.empty() ? nullptr : always.data();
