@@ -20,8 +20,9 @@ namespace rrtx {
 // Spheres and moving spheres of ordinary size go into a uniform grid (cell = 2 x their median
 // extent; measured on final.txt: 1.5 / 2 / 2.5 / 3.5 -> 53.2 / 49.5 / 51.5 / 74 ms at spp 504); primitives
 // larger than 1.6 cells (RRTX_GRID_LARGE; with the three r = 1 spheres of final.txt gridded the grid has
-// three layers of cells instead of one: 66.8 against 41.1 ms), spheres smaller than a fiftieth of a cell
-// and all triangles go into the "always" list.  Every gridded primitive is entered into all cells its box, INFLATED, overlaps.
+// three layers of cells instead of one: 66.8 against 41.1 ms - the factor is only raised, to 4 and 10, when
+// the always-list would overflow), spheres smaller than a fiftieth of a cell and the triangles the bound
+// below does not cover go into the "always" list.  Every gridded primitive is entered into all cells its box, INFLATED, overlaps.
 // By how much: the reference's discriminant, evaluated in floating point, can be >= 0 only if the
 // ray's line passes within sqrt(r^2 + m) of the centre, m = 32 eps (|o - c|^2 + r^2) (a bound on the
 // rounding error of (oc.d)^2 - |d|^2 (|oc|^2 - r^2) relative to |d|^2; 24 eps by the usual gamma_n
@@ -118,11 +119,12 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
     double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
     if (!(cell > 0) || !std::isfinite(cell)) return false;
 
-    const double large = getenv("RRTX_GRID_LARGE") ? atof(getenv("RRTX_GRID_LARGE")) : 1.6;
+    const double large0 = getenv("RRTX_GRID_LARGE") ? atof(getenv("RRTX_GRID_LARGE")) : 1.6;
+    double large = large0;
     const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
     const double cam_o[3] = {(double)cam.origin[0], (double)cam.origin[1], (double)cam.origin[2]};
     std::vector<double> delta(boxes.size(), 0.0); // per primitive: how far its box is inflated
-    for (int attempt = 0; attempt < 16; ++attempt) {
+    for (int attempt = 0; attempt < 48; ++attempt) {
         // half diagonal and centre of what would be gridded (by size alone: the inflation comes next)
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         size_t n_sized = 0;
@@ -175,7 +177,13 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             break;
         }
         if (!built) {
-            cell *= 1.6; // larger cells: "large" primitives become ordinary, inflations relatively smaller
+            // too many primitives left over for the always-list: first let larger ones into the cells (a mesh of
+            // small triangles among spheres ten times their size: 32 against 87 ms with the cells kept small),
+            // then try larger cells, where "large" primitives become ordinary and inflations relatively smaller
+            if (large < 9.9)
+                large *= 2.5;
+            else
+                large = large0, cell *= 1.6;
             continue;
         }
         std::vector<int> gridded;
@@ -201,7 +209,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             total *= dims[k];
         }
         if (total > 262144.0 || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
-            cell *= 1.6;
+            large = large0, cell *= 1.6;
             continue;
         }
         hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
