@@ -104,7 +104,8 @@ typedef struct rrtx_params {
     int32_t max_depth;                 /* -d                                               */
     int32_t use_bvh;                   /* -b clears it (main.cpp:67,90).  Non-zero: segments are resolved
                                           through an acceleration grid when the scene allows one
-                                          (rrtx_stats.accel_cells); zero: the hittable_list scan.
+                                          (rrtx_stats.accel_cells; spheres always, triangle meshes
+                                          in fp64 only); zero: the hittable_list scan.
                                           Same image either way, bit for bit.                    */
     int32_t threads_x, threads_y;      /* -tx / -ty: accepted; reported in the stats line    */
     int32_t fp64;                      /* 0 = `rrt` (float), 1 = `rrtd` (double)            */
