@@ -61,7 +61,7 @@ struct rrtx_ctx {
     // scene
     bool have_scene = false;
     int n_sph = 0, n_sph_padded = 0, n_msph = 0, n_tri = 0, n_mat = 0;
-    void *d_hot = nullptr, *d_filter = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_mat = nullptr;
+    void *d_hot = nullptr, *d_filter = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_tri_scan = nullptr, *d_mat = nullptr;
     bool tail_ok = false;    // scene magnitudes allow the tail kernel's split scan (no NaN roots possible)
     bool use_filter = false; // conservative scan filter valid for the current scene and not disabled
     int lds_mode = 0;        // 0 scalar loads, 1 alternate scalar / LDS, 2 LDS only
@@ -127,10 +127,10 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     const bool filter_ok = packed.filter_ok;
 
     RRTX_HIP(hipSetDevice(c->device));
-    void *old[6] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat};
+    void *old[7] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat};
     for (void *p : old)
         if (p) (void)hipFree(p);
-    c->d_hot = c->d_filter = c->d_cold = c->d_msph = c->d_tri = c->d_mat = nullptr;
+    c->d_hot = c->d_filter = c->d_cold = c->d_msph = c->d_tri = c->d_tri_scan = c->d_mat = nullptr;
     c->have_scene = false;
 
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -148,6 +148,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if ((rc = up(&c->d_cold, hcold.data(), hcold.size() * sizeof(SphereCold<F>)))) return rc;
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
+    if ((rc = up(&c->d_tri_scan, packed.tri_scan.data(), packed.tri_scan.size() * sizeof(TriScanRec<F>)))) return rc;
     if ((rc = up(&c->d_mat, hmat.data(), hmat.size() * sizeof(MaterialRec<F>)))) return rc;
     c->tail_ok = packed.tail_ok;
     // accelerated closest hit (the reference's -b switches its BVH off, main.cpp:67,90)
@@ -191,6 +192,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.sph_cold = (const SphereCold<F> *)c->d_cold;
     P.msph = (const MovingSphereRec<F> *)c->d_msph;
     P.tri = (const TriangleRec<F> *)c->d_tri;
+    P.tri_scan = (const TriScanRec<F> *)c->d_tri_scan;
     P.mat = (const MaterialRec<F> *)c->d_mat;
     P.n_sph = c->n_sph, P.n_sph_padded = c->n_sph_padded, P.n_msph = c->n_msph, P.n_tri = c->n_tri;
     memcpy(&P.cam, c->cam_bytes, sizeof(CameraRec<F>));
@@ -372,7 +374,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -412,8 +414,9 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         (void)hipFree(c->d_plist);
         c->d_plist = nullptr;
     }
-    // (a LIST pass tests every moving sphere and triangle per camera ray: with a mesh in the grid the walk is the cheaper way)
-    if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && !(c->accel && c->n_tri + c->n_msph > 64)) {
+    // (a LIST pass tests every moving sphere and triangle per camera ray, with the few lanes that hold one: with a
+    // mesh in the scene the walk resp. the scan pass, which has to go through them anyway, is the cheaper way)
+    if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && c->n_tri + c->n_msph <= 64) {
         const size_t bytes = (size_t)c->local_rows * c->p.image_width * kPlistStride * sizeof(uint16_t);
         uint16_t *pl = nullptr;
         RRTX_HIP(hipMalloc((void **)&pl, bytes));

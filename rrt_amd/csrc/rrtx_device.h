@@ -72,6 +72,13 @@ template <typename F> struct TriangleRec {
     F n[3];  // get_normal()                  (triangle.h:9-15)
     int32_t mat;
 };
+// What the scan's triangle phase reads per triangle: the nine numbers of the test in ONE aligned
+// s_load_dwordx16 (fp64: two) instead of four scalar loads of the 52-byte TriangleRec's fields (a mesh of
+// 27 k triangles: 502 -> 486 ms; dropping the camera-ray LIST passes, which walk all triangles with a
+// quarter of the lanes, brought the larger step: 486 -> 363 ms).
+template <typename F> struct alignas(16 * sizeof(F)) TriScanRec {
+    F v0[3], e1[3], e2[3], pad[7];
+};
 template <typename F> struct alignas(4 * sizeof(F)) MaterialRec {
     F r, g, b;
     F param; // metal: min(fuzz,1) (material.h:48) | dielectric: ir
@@ -133,6 +140,7 @@ template <typename F> struct KernelParams {
     const SphereCold<F> *sph_cold;
     const MovingSphereRec<F> *msph;
     const TriangleRec<F> *tri;
+    const TriScanRec<F> *tri_scan; // the same triangles, as the scan reads them
     const MaterialRec<F> *mat;
     int32_t n_sph, n_sph_padded, n_msph, n_tri;
     CameraRec<F> cam;

@@ -643,10 +643,18 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 }
             }
             // phase 1c: triangles
+            // (one aligned s_load_dwordx16 per triangle through the constant address space, see TriScanRec)
+            const RRTX_CONST_AS TriScanRec<F> *tri_scalar = (const RRTX_CONST_AS TriScanRec<F> *)P.tri_scan;
             for (int t = 0; t < n_tri; ++t) {
                 if (__ballot(cnt >= (uint32_t)kCap) != 0ull) drain();
+                // (as one vector: the compiler otherwise loads field by field, where each is first used; loading
+                // one triangle ahead gained nothing: 362 vs 355 ms)
+                typedef F Vec16 __attribute__((ext_vector_type(16)));
+                const Vec16 q = *(const RRTX_CONST_AS Vec16 *)&tri_scalar[t];
+                TriScanRec<F> rec;
+                rec.v0[0] = q[0], rec.v0[1] = q[1], rec.v0[2] = q[2], rec.e1[0] = q[3], rec.e1[1] = q[4], rec.e1[2] = q[5], rec.e2[0] = q[6], rec.e2[1] = q[7], rec.e2[2] = q[8];
                 F dummy;
-                if (triangle_test<F, false>(P.tri[t], path, t_min, best.t, dummy)) {
+                if (triangle_test<F, false>(rec, path, t_min, best.t, dummy)) {
                     my_cand[cnt * 64] = (uint32_t)(tri_base + t);
                     cnt += 1;
                 }

@@ -47,6 +47,7 @@ template <typename F> struct PackedScene {
     std::vector<SphereCold<F>> cold;
     std::vector<MovingSphereRec<F>> ms;
     std::vector<TriangleRec<F>> tri;
+    std::vector<TriScanRec<F>> tri_scan;
     CameraRec<F> cam;
     int n_pad = 0;          // spheres padded to a multiple of kSpherePad with never-hit records
     bool filter_ok = true;  // magnitudes within the filter's proven range
@@ -182,6 +183,12 @@ template <typename F> const char *pack_scene(const rrtx_scene_desc *s, PackedSce
         pack_unit<F>(cr, t.n);
         t.mat = tri[i].material_idx;
         htri[i] = t;
+    }
+    out.tri_scan.clear(), out.tri_scan.resize(htri.size());
+    for (size_t i = 0; i < htri.size(); ++i) {
+        TriScanRec<F> r = {};
+        for (int k = 0; k < 3; ++k) r.v0[k] = htri[i].v0[k], r.e1[k] = htri[i].e1[k], r.e2[k] = htri[i].e2[k];
+        out.tri_scan[i] = r;
     }
 
     out.n_pad = n_pad;

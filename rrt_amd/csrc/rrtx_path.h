@@ -208,7 +208,7 @@ template <typename F> RRTX_DEV V3<F> msphere_center(const MovingSphereRec<F> &m,
 }
 
 // triangle.h:35-75.  stage 0: up to the u/v rejections (phase 1); stage 1: full test (phase 2).
-template <typename F, bool FULL> RRTX_DEV bool triangle_test(const TriangleRec<F> &tr, const Path<F> &p, F t_min, F t_max, F &t_out)
+template <typename F, bool FULL, typename TR> RRTX_DEV bool triangle_test(const TR &tr, const Path<F> &p, F t_min, F t_max, F &t_out) // TR: TriangleRec<F> in any address space
 {
     const F EPS = (F)0.0000001;
     V3<F> e1 = ld3<F>(tr.e1), e2 = ld3<F>(tr.e2);
