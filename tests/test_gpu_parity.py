@@ -542,6 +542,24 @@ def test_a_triangle_mesh_is_gridded_in_fp64_and_scanned_in_fp32(gpu, tmp_path):
     assert st["accel_cells"] == 0 and np.array_equal(fb, want32)
 
 
+def test_random_launch_shapes_give_the_same_image_in_both_modes(gpu):
+    """A small differential fuzz (tools/fuzz_modes.py runs hundreds): frame sizes, spp, chunking, shards, depth and
+    hand-off parameters drawn at random; the grid mode (hand-off and resume pass included) must reproduce
+    the list scan's image exactly."""
+    rng = np.random.default_rng(3)
+    for case in range(24):
+        fp64 = bool(rng.integers(2))
+        w, h, spp = int(rng.integers(8, 300)), int(rng.integers(8, 200)), int(rng.choice([1, 3, 8, 9, 17]))
+        kw = dict(sample_chunk=int(rng.choice([0, -1, 1, 3, 8])), handoff_lanes=int(rng.choice([0, 1, 7, 64])), handoff_iters=int(rng.choice([0, 1, 8, 50])), tile_rows=int(rng.choice([1, 4, 8])))
+        shards = int(rng.choice([1, 2, 3]))
+        rank = int(rng.integers(shards))
+        depth = int(rng.choice([50, 5, 1]))
+        a, _ = _render(gpu, SCENES["final"], w, h, spp, depth, fp64=fp64, shard_rank=rank, shard_count=shards, **kw)
+        b, st = _render(gpu, SCENES["final"], w, h, spp, depth, fp64=fp64, use_bvh=True, shard_rank=rank, shard_count=shards, **kw)
+        assert st["accel_cells"] > 0
+        assert np.array_equal(a, b), (case, fp64, w, h, spp, depth, rank, shards, kw)
+
+
 def test_small_scenes_keep_the_list_scan(gpu):
     for name in ("test1", "test2", "test3", "xform"):
         fb, st = _render(gpu, SCENES[name], 64, 40, 4, use_bvh=True)
