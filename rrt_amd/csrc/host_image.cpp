@@ -1,7 +1,9 @@
 // Host side of the seam: what main.cpp does with the framebuffer Rrt::render returns —
 // the gamma-2 8-bit quantiser (color.h:8-23, rtweekend.h:93-98), the row flip
 // (main.cpp:143,153), ASCII PPM to stdout (main.cpp:142-148) and a PNG file (main.cpp:164).
-// The PNG encoder is our own (zlib deflate, filter 0); decoded pixels are what matters.
+// The PNG encoder is our own (zlib deflate, filter 0; bands of rows deflated on several threads and joined
+// into one zlib stream); decoded pixels are what matters.  SURVEY.md 8(f) N4: the encoder must not be what
+// a batch of frames waits for - single-threaded deflate of a 1200x800 frame took longer than its render.
 #include <zlib.h>
 
 #include <climits>
@@ -9,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrtx.h"
@@ -41,14 +44,36 @@ template <typename F> inline uint8_t quantise_channel(F sum, F scale)
     return (uint8_t)as_int;
 }
 
+// Work over n rows is cut into bands, one thread each: up to 16 threads, at least 256 KB of work per band
+// (small images stay on the caller's thread).
+int band_count(int n, size_t work_per_row)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t bands = hw ? (hw > 16 ? 16 : hw) : 1;
+    const size_t by_work = (size_t)n * work_per_row / ((size_t)1 << 18);
+    if (bands > by_work) bands = by_work;
+    if (bands > (size_t)n) bands = (size_t)n;
+    return bands < 2 ? 1 : (int)bands;
+}
+// body(first_row, last_row, band) for every band; band 0 on the calling thread
+template <typename Body> void in_bands(int n, int bands, Body body)
+{
+    std::vector<std::thread> pool;
+    for (int b = 1; b < bands; ++b) pool.emplace_back(body, (int)((int64_t)n * b / bands), (int)((int64_t)n * (b + 1) / bands), b);
+    body(0, (int)((int64_t)n / bands), 0);
+    for (std::thread &th : pool) th.join();
+}
+
 template <typename F> void quantise_image(const F *fb, int w, int h, int spp, uint8_t *rgb)
 {
     const F scale = (F)1.0 / spp; // color.h:15
-    for (int out_row = 0; out_row < h; ++out_row) {
-        const F *src = fb + (size_t)(h - 1 - out_row) * w * 3; // main.cpp:153: top row = fb row h-1
-        uint8_t *dst = rgb + (size_t)out_row * w * 3;
-        for (int k = 0; k < w * 3; ++k) dst[k] = quantise_channel<F>(src[k], scale);
-    }
+    in_bands(h, band_count(h, (size_t)w * 3 * 8), [=](int first, int last, int) {
+        for (int out_row = first; out_row < last; ++out_row) {
+            const F *src = fb + (size_t)(h - 1 - out_row) * w * 3; // main.cpp:153: top row = fb row h-1
+            uint8_t *dst = rgb + (size_t)out_row * w * 3;
+            for (int k = 0; k < w * 3; ++k) dst[k] = quantise_channel<F>(src[k], scale);
+        }
+    });
 }
 
 void put_be32(std::vector<uint8_t> &v, uint32_t x)
@@ -87,15 +112,33 @@ int rrtx_write_ppm(const char *path, const uint8_t *rgb, int w, int h)
     if (!rgb || w < 1 || h < 1) return RRTX_E_INVALID;
     FILE *f = (!path || std::strcmp(path, "-") == 0) ? stdout : std::fopen(path, "w");
     if (!f) return RRTX_E_IO;
-    // main.cpp:142 + color.h:31: "P3\nW H\n255\n" then one "r g b\n" line per pixel
-    std::string text;
-    text.reserve((size_t)w * h * 12 + 32);
-    text += "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-    char line[16];
-    for (size_t p = 0; p < (size_t)w * h; ++p) {
-        int n = std::snprintf(line, sizeof line, "%u %u %u\n", rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]);
-        text.append(line, (size_t)n);
-    }
+    // main.cpp:142 + color.h:31: "P3\nW H\n255\n" then one "r g b\n" line per pixel.  The text of a 4K frame is
+    // ~ 90 MB: bands of rows are formatted on several threads from a table of the 256
+    // decimal strings, then written in order.
+    char dec[256][4];
+    int dec_len[256];
+    for (int v = 0; v < 256; ++v) dec_len[v] = std::snprintf(dec[v], sizeof dec[v], "%d", v);
+    const int bands = band_count(h, (size_t)w * 3 * 16);
+    std::vector<std::string> part((size_t)bands);
+    in_bands(h, bands, [&](int first, int last, int b) {
+        std::string &t = part[(size_t)b];
+        t.resize((size_t)(last - first) * w * 12);
+        char *o = &t[0];
+        for (size_t p = (size_t)first * w; p < (size_t)last * w; ++p) {
+            for (int k = 0; k < 3; ++k) {
+                const uint8_t v = rgb[3 * p + k];
+                std::memcpy(o, dec[v], 3); // (copies 3 bytes, advances by the true length)
+                o += dec_len[v];
+                *o++ = k == 2 ? '\n' : ' ';
+            }
+        }
+        t.resize((size_t)(o - &t[0]));
+    });
+    std::string text = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
+    size_t total = text.size();
+    for (const std::string &t : part) total += t.size();
+    text.reserve(total);
+    for (const std::string &t : part) text += t;
     const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
     if (f != stdout)
         std::fclose(f);
@@ -107,16 +150,49 @@ int rrtx_write_ppm(const char *path, const uint8_t *rgb, int w, int h)
 int rrtx_write_png(const char *path, const uint8_t *rgb, int w, int h)
 {
     if (!path || !rgb || w < 1 || h < 1) return RRTX_E_INVALID;
-    // raw scanlines, each prefixed by filter type 0
-    std::vector<uint8_t> raw((size_t)h * ((size_t)w * 3 + 1));
-    for (int y = 0; y < h; ++y) {
-        uint8_t *row = raw.data() + (size_t)y * ((size_t)w * 3 + 1);
-        row[0] = 0;
-        std::memcpy(row + 1, rgb + (size_t)y * w * 3, (size_t)w * 3);
+    // Raw scanlines, each prefixed by filter type 0, deflated in bands of rows: every band is a raw deflate
+    // stream of its own (no shared dictionary), all but the last ended with a full flush - byte aligned, not
+    // final - so that their concatenation behind one zlib header is ONE valid stream; its Adler-32 is
+    // combined from the bands'.
+    const size_t stride = (size_t)w * 3 + 1;
+    const int bands = band_count(h, stride * 8);
+    std::vector<std::vector<uint8_t>> zb((size_t)bands);
+    std::vector<uLong> adler((size_t)bands, 0);
+    std::vector<size_t> raw_len((size_t)bands, 0);
+    std::vector<int> ok_band((size_t)bands, 0);
+    auto deflate_band = [&](int first, int last, int b) {
+        std::vector<uint8_t> raw((size_t)(last - first) * stride);
+        for (int y = first; y < last; ++y) {
+            uint8_t *row = raw.data() + (size_t)(y - first) * stride;
+            row[0] = 0;
+            std::memcpy(row + 1, rgb + (size_t)y * w * 3, (size_t)w * 3);
+        }
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+        std::vector<uint8_t> &out = zb[(size_t)b];
+        out.resize(deflateBound(&zs, (uLong)raw.size()) + 64);
+        zs.next_in = raw.data(), zs.avail_in = (uInt)raw.size();
+        zs.next_out = out.data(), zs.avail_out = (uInt)out.size();
+        const int rc = deflate(&zs, b == bands - 1 ? Z_FINISH : Z_FULL_FLUSH);
+        const bool fine = (b == bands - 1 ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0;
+        out.resize(out.size() - zs.avail_out);
+        deflateEnd(&zs);
+        adler[(size_t)b] = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+        raw_len[(size_t)b] = raw.size();
+        ok_band[(size_t)b] = fine ? 1 : 0;
+    };
+    in_bands(h, bands, deflate_band);
+    std::vector<uint8_t> z;
+    z.push_back(0x78), z.push_back(0x9C); // zlib header: deflate, 32 K window, default level, no dictionary
+    uLong sum = adler32(0L, Z_NULL, 0);
+    for (int b = 0; b < bands; ++b) {
+        if (!ok_band[(size_t)b]) return RRTX_E_IO;
+        z.insert(z.end(), zb[(size_t)b].begin(), zb[(size_t)b].end());
+        sum = b == 0 ? adler[0] : adler32_combine(sum, adler[(size_t)b], (z_off_t)raw_len[(size_t)b]);
     }
-    uLongf zlen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(zlen);
-    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return RRTX_E_IO;
+    put_be32(z, (uint32_t)sum);
+    const size_t zlen = z.size();
 
     std::vector<uint8_t> file;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};

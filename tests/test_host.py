@@ -139,6 +139,27 @@ def test_png_decodes_to_the_same_pixels(tmp_path):
     assert np.array_equal(np.asarray(Image.open(str(out))), noise)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (3, 4000), (2160, 3840), (1001, 777), (5000, 2)])
+def test_png_bands_join_into_one_valid_stream(tmp_path, shape):
+    """Large images are deflated in bands of rows on several threads and joined behind one zlib header
+    (host_image.cpp); PIL, i.e. zlib's inflate with its Adler-32 check, must decode exactly the input:
+    noise (incompressible), a smooth gradient and rows of constants, for frames with fewer rows than
+    threads, one pixel, and a 4K frame."""
+    from PIL import Image
+
+    h, w = shape
+    rng = np.random.default_rng(h * 7919 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for k, img in enumerate((rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8),
+                             np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], axis=-1).astype(np.uint8),
+                             np.full((h, w, 3), 200, dtype=np.uint8))):
+        out = tmp_path / ("b%d.png" % k)
+        rrt_amd.write_png(str(out), np.ascontiguousarray(img))
+        back = Image.open(str(out))
+        back.load()  # (decodes and verifies the checksums)
+        assert back.size == (w, h) and np.array_equal(np.asarray(back), img), (shape, k)
+
+
 @pytest.mark.parametrize("binary", ["rrt", "rrtd"])
 def test_cli_argument_errors_exit_like_the_reference(binary, tmp_path):
     exe = os.path.join(ROOT, binary)
