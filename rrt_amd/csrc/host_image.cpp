@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -59,8 +60,14 @@ int band_count(int n, size_t work_per_row)
 template <typename Body> void in_bands(int n, int bands, Body body)
 {
     std::vector<std::thread> pool;
-    for (int b = 1; b < bands; ++b) pool.emplace_back(body, (int)((int64_t)n * b / bands), (int)((int64_t)n * (b + 1) / bands), b);
+    int started = 1;
+    try {
+        for (; started < bands; ++started) pool.emplace_back(body, (int)((int64_t)n * started / bands), (int)((int64_t)n * (started + 1) / bands), started);
+    }
+    catch (const std::system_error &) { // no more threads to be had: the caller does the remaining bands itself
+    }
     body(0, (int)((int64_t)n / bands), 0);
+    for (int b = started; b < bands; ++b) body((int)((int64_t)n * b / bands), (int)((int64_t)n * (b + 1) / bands), b);
     for (std::thread &th : pool) th.join();
 }
 
