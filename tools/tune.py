@@ -1,6 +1,6 @@
 """Developer script (GPU box): time library variants / tuning parameters on final.txt.
 
-  python tools/tune.py [lib=build/librrtx_x.so] [size=1200x800] [spp=8,48,504] [key=v1,v2,...]...
+  python tools/tune.py [lib=build/librrtx_x.so] [scene=final] [size=1200x800] [spp=8,48,504] [key=v1,v2,...]...
 Every `key` is an Rrt() keyword (taper_samples, handoff_iters, handoff_lanes, list_passes, sample_chunk, flags);
 the cartesian product of the value lists is timed (min of 3 launches after a warm-up) and a checksum of
 the frame printed, which must not change.
@@ -17,8 +17,9 @@ import rrt_amd
 from _oracle import scene_path
 W, H = (int(x) for x in args.pop("size", "1200x800").split("x"))
 spps = [int(x) for x in args.pop("spp", "8,48,504").split(",")]
+scene = args.pop("scene", "final")
 keys = sorted(args)
-s = rrt_amd.Scene(scene_path("final"), W, H)
+s = rrt_amd.Scene(scene_path(scene), W, H)
 buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 for combo in itertools.product(*[[int(v) for v in args[k].split(",")] for k in keys]):
     kw = dict(zip(keys, combo))
