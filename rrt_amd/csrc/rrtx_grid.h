@@ -46,7 +46,7 @@ namespace rrtx {
 // inserting the computed (t, u, v) into o + t d = v0 + u e1 + v e2 leaves a residual of at most
 //     R = rho / (1 - rho) (3 |s| + t |d| + |e1| + |e2|):
 // the reported hit point lies within R of the triangle (u, v in [0, 1]).  A triangle is gridded - entered
-// in every cell its box, inflated by R + a hundredth of a cell, overlaps - if rho <= 1e-6 for every ray
+// in every cell its box, inflated by R + a hundredth of a cell, overlaps - if rho <= 1e-4 for every ray
 // the walk answers (|d|^2 <= dir2_max = 1e6, |s| and t |d| within far + the grid's half diagonal), the
 // inflation stays under half a cell and its box under `large` cells; everything else stays in the
 // always-list.  In fp64 rho ~ 2e-8 |d| |e1| |e2|: meshes are gridded.  In fp32 rho ~ 10 |d| |e1| |e2|: the
@@ -106,7 +106,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         }
         b.e1e2 = std::sqrt(l1) * std::sqrt(l2), b.e_sum = std::sqrt(l1) + std::sqrt(l2);
         b.r = 1e300, b.idx = tri_base + i, b.is_tri = true; // (r: never "tiny")
-        b.candidate = 16 * eps0 * std::sqrt(kGridDir2Max) * b.e1e2 / 1e-7 <= 1e-6; // rho, see above
+        b.candidate = 16 * eps0 * std::sqrt(kGridDir2Max) * b.e1e2 / 1e-7 <= 1e-4; // rho, see above
         boxes.push_back(b);
     }
     std::vector<double> ext, sorted;

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from _oracle import GOLDEN, ROOT, Oracle, scene_path
+from _oracle import GOLDEN, ROOT, Oracle, mesh_scene, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -496,38 +496,12 @@ def test_accelerated_closest_hit_is_bit_identical(gpu, fp64):
     assert np.array_equal(fb, Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)[0])
 
 
-def _mesh_scene(path, nu=16, nv=32):
-    """A UV sphere of nu x nv quads as ONE obj, instanced three times (translated, scaled, rotated), over a
-    field of small spheres on the usual ground: 3 x 960 triangles for the defaults."""
-    rng = np.random.default_rng(9)
-    lines = ["camera 6 2.5 7 0 0.8 0 0 1 0 35 0.05 9", "material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 0.05", "material g dielectric 1.5",
-             "material r lambertian 0.8 0.2 0.2", "sphere 0 -1000 0 1000 a"]
-    for i in range(-5, 5):
-        for j in range(-5, 5):
-            lines.append("sphere %r 0.2 %r 0.2 %s" % (i + 0.9 * float(rng.uniform()), j + 0.9 * float(rng.uniform()), "amg"[(i + j) % 3]))
-    verts = [(np.sin(np.pi * i / nu) * np.cos(2 * np.pi * j / nv), np.cos(np.pi * i / nu), np.sin(np.pi * i / nu) * np.sin(2 * np.pi * j / nv)) for i in range(nu + 1) for j in range(nv)]
-    tris = []
-    for i in range(nu):
-        for j in range(nv):
-            a, b, c, d = i * nv + j, i * nv + (j + 1) % nv, (i + 1) * nv + j, (i + 1) * nv + (j + 1) % nv
-            if i > 0:
-                tris.append((a, c, b))
-            if i < nu - 1:
-                tris.append((b, c, d))
-    lines.append("obj_beg %d %d" % (len(verts), len(tris)))
-    lines += ["obj_vtx %r %r %r" % tuple(float(x) for x in v) for v in verts]
-    lines += ["obj_tri %d %d %d" % t for t in tris]
-    lines += ["obj_end", "obj 0 r t 0 1.0 0", "obj 0 m s 0.6 0.6 0.6 t 2.2 0.6 1.5", "obj 0 g s 0.7 0.5 0.7 r 40 0 0 1 t -2.0 0.7 1.0"]
-    open(path, "w").write("\n".join(lines) + "\n")
-    return str(path), 3 * len(tris)
-
-
 def test_a_triangle_mesh_is_gridded_in_fp64_and_scanned_in_fp32(gpu, tmp_path):
     """SURVEY.md 8(f) N2.  The bound on Moeller-Trumbore's residual (rrtx_grid.h) admits triangles to the
     grid in fp64 and none of practical size in fp32: the fp64 render walks the grid (cells reported, walk
     verified against the sequential scan, image equal to the oracle's), the fp32 render of the same file
     keeps the list scan - and equals the oracle's as well."""
-    f, n_tri = _mesh_scene(tmp_path / "mesh.txt")
+    f, n_tri = mesh_scene(tmp_path / "mesh.txt")
     w, h, spp = 96, 64, 4
     want, stats = Oracle(f, w, h, True).render(spp, 50, 1984, order=1, chunk=8)
     fb, st = _render(gpu, f, w, h, spp, fp64=True, use_bvh=True)

@@ -240,6 +240,25 @@ def test_kernel_source_compiled_for_the_host_equals_the_oracle(host_render, name
     assert np.array_equal(host_render(path, w, h, 3, 2, fp64, -1, 1)[0], want)
 
 
+def test_mesh_scene_on_the_host_grid_in_fp64_list_in_fp32(host_render, tmp_path):
+    """SURVEY.md 8(f) N2 on the CPU tier: a mesh of 672 triangles (obj instances) through the kernel's path
+    arithmetic compiled for the host.  fp64: the grid is built, nearly every segment is walked, radiance
+    bit-identical to the oracle; fp32: the residual bound admits no triangle, no grid, the list is
+    scanned - and equals the oracle too."""
+    from _oracle import mesh_scene
+
+    f, n_tri = mesh_scene(tmp_path / "mesh.txt", 8, 16)
+    w, h, spp = 36, 24, 3
+    for fp64 in (True, False):
+        want, st = Oracle(f, w, h, fp64).render(spp, 50, 1984, order=1, chunk=3)
+        for mode in (0, 1):
+            got, info = host_render(f, w, h, spp, 50, fp64, 3, mode)
+            assert info["segments"] == st["segments"] and np.array_equal(got, want), (fp64, mode)
+            if mode == 1:
+                assert (info["grid"] > 0) == fp64, (fp64, info)
+                assert not fp64 or info["walked"] > 0.9 * info["segments"]
+
+
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     """Sanitizers run on the CPU build only (the GPU pool has none): the scene parser on every scene
     and on malformed input, the quantiser and the PNG / PPM writers; and the grid builder + grid walk

@@ -6,11 +6,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import rrt_amd
 from rrt_amd import _lib
-from test_gpu_parity import _mesh_scene
+from _oracle import mesh_scene
 a = [int(x) for x in sys.argv[1:]]
 nu, nv = (a[0], a[1]) if len(a) >= 2 else (16, 32)
 W, H, spp = (a[2], a[3], a[4]) if len(a) >= 5 else (600, 400, 16)
-f, n_tri = _mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), nu, nv)
+f, n_tri = mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), nu, nv)
 for fp64 in (True, False):
     sc = rrt_amd.Scene(f, W, H, fp64=fp64)
     out = {}
