@@ -231,11 +231,11 @@ class Reference:
         return self.L.ref_rng_probe(seed, pixel, sample, n)
 
 
-def mesh_scene(path, nu=16, nv=32):
+def mesh_scene(path, nu=16, nv=32, camera="camera 6 2.5 7 0 0.8 0 0 1 0 35 0.05 9"):
     """A UV sphere of nu x nv quads as ONE obj, instanced three times (translated, scaled, rotated), over a
     field of small spheres on the usual ground: 3 x 960 triangles for the defaults."""
     rng = np.random.default_rng(9)
-    lines = ["camera 6 2.5 7 0 0.8 0 0 1 0 35 0.05 9", "material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 0.05", "material g dielectric 1.5",
+    lines = [camera, "material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 0.05", "material g dielectric 1.5",
              "material r lambertian 0.8 0.2 0.2", "sphere 0 -1000 0 1000 a"]
     for i in range(-5, 5):
         for j in range(-5, 5):

@@ -514,6 +514,12 @@ def test_a_triangle_mesh_is_gridded_in_fp64_and_scanned_in_fp32(gpu, tmp_path):
     want32 = Oracle(f, w, h, False).render(spp, 50, 1984, order=1, chunk=8)[0]
     fb, st = _render(gpu, f, w, h, spp, use_bvh=True)
     assert st["accel_cells"] == 0 and np.array_equal(fb, want32)
+    # camera rays longer than the |d| the inflation is proven for (focus distance 4000: |d| ~ 4000) take the list scan
+    f2, _ = mesh_scene(tmp_path / "mesh_far_focus.txt", camera="camera 6 2.5 7 0 0.8 0 0 1 0 35 0.0 4000")
+    want2, stats2 = Oracle(f2, 64, 40, True).render(2, 50, 1984, order=1, chunk=2)
+    fb, st = _render(gpu, f2, 64, 40, 2, fp64=True, use_bvh=True)
+    assert st["accel_cells"] > 0 and st["scanned_segments"] >= 64 * 40 * 2 and st["segments"] == stats2["segments"]
+    assert np.array_equal(fb, want2)
 
 
 def test_random_launch_shapes_give_the_same_image_in_both_modes(gpu):
