@@ -629,9 +629,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 }
             }
             // phase 1b: moving spheres (center depends on the ray's time: per-lane)
+            const RRTX_CONST_AS MovingSphereRec<F> *msph_scalar = (const RRTX_CONST_AS MovingSphereRec<F> *)P.msph; // (uniform index: s_load)
             for (int m = 0; m < n_msph; ++m) {
                 if (__ballot(cnt >= (uint32_t)kCap) != 0ull) drain();
-                const MovingSphereRec<F> ms = P.msph[m];
+                const RRTX_CONST_AS MovingSphereRec<F> &ms = msph_scalar[m];
                 const V3<F> cen = msphere_center<F>(ms, path.tm);
                 const F ocx = path.o.x - cen.x, ocy = path.o.y - cen.y, ocz = path.o.z - cen.z;
                 const F half_b = ocx * path.d.x + ocy * path.d.y + ocz * path.d.z;

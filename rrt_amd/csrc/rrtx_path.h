@@ -201,7 +201,7 @@ template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const 
     best.idx = idx;
 }
 
-template <typename F> RRTX_DEV V3<F> msphere_center(const MovingSphereRec<F> &m, F tm) // moving_sphere.h:27-30
+template <typename F, typename MR> RRTX_DEV V3<F> msphere_center(const MR &m, F tm) // moving_sphere.h:27-30; MR: MovingSphereRec<F> in any address space
 {
     F s = (tm - m.t0) / m.dt;
     return mk<F>(m.c0[0] + s * m.dc[0], m.c0[1] + s * m.dc[1], m.c0[2] + s * m.dc[2]);
