@@ -169,7 +169,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             if ((rc = up((void **)&c->d_grid_cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
             if ((rc = up((void **)&c->d_grid_cell_prims, cell_prims.data(), cell_prims.size() * 2))) return rc;
             if ((rc = up((void **)&c->d_grid_always, always.data(), always.size() * 4))) return rc;
-            c->n_grid_cells = G.dims[0] * G.dims[1] * G.dims[2]; // (cell_start holds G.levels offsets per cell, + 1)
+            c->n_grid_cells = (int)cell_start.size() - 1;
             c->n_grid_prims = (int)cell_start.back();
             memcpy(c->grid_bytes, &G, sizeof G);
             c->accel = true;

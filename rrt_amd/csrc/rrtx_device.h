@@ -114,12 +114,6 @@ template <typename F> struct GridRec {
     F slack, slack1, half_diag; // the walk continues slack + slack1 (|o - center| + half_diag) world units beyond the closest hit so far
     int32_t max_steps;   // bound on the trips of the walk (cells stepped through + primitives tested)
     F dir2_max;          // rays with |d|^2 above this take the list scan: the inflation of gridded triangles is proven up to it
-    // Distance levels (large fp32 worlds): a cell's entries are sorted by level, cell_start has `levels` offsets per
-    // cell, and a ray that leaves a cell at distance s from its origin tests the levels l with l == 0 or
-    // s > level_dist[l - 1] only: a sphere's box is inflated by the error of its exact test, which grows with the
-    // distance between ray origin and sphere - near the origin the cells stay tight.
-    int32_t levels;      // 1..4
-    F level_dist[3];
 };
 
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,

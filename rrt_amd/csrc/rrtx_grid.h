@@ -8,7 +8,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <limits>
 #include <vector>
 
 #include "rrtx_device.h"
@@ -144,75 +143,36 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         // inflation of a typical primitive under a tenth of a cell, else three; always past the camera.
         double far = 0, rho_max = 0;
         bool built = false;
-        int levels = 1;
-        double level_D[4] = {0, 0, 0, 0}, margin = 0;
-        std::vector<double> delta0(boxes.size(), 0.0); // inflation at level 0 (= delta[] when there is one level)
-        auto sphere_delta = [&](size_t i, double D) {
-            const double r = boxes[i].r, m = 32 * eps * (D * D + r * r);
-            return std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
-        };
         for (double mult : {6.0, 3.0}) {
             far = std::max(mult * hd, 1.25 * cam_dist);
             const double far_cap = sizeof(F) == 4 ? 1e6 : 1e50;
             if (far > far_cap) far = far_cap;
             const double R = far + hd; // |o - c| of any ray the grid answers
-            // inflation for the whole range (the top level), and is it small enough for one level to do?
-            std::vector<double> typical;
-            double r_max = 0, d_top_max = 0;
+            always.clear();
+            std::vector<double> infl;
+            rho_max = 0;
             for (size_t i = 0; i < boxes.size(); ++i) {
+                bool grid_it;
                 if (boxes[i].is_tri) {
                     const double rho = 16 * eps * std::sqrt(kGridDir2Max) * boxes[i].e1e2 / 1e-7;
                     const double resid = rho < 0.5 ? rho / (1 - rho) * (4 * R + boxes[i].e_sum) : 1e300;
                     delta[i] = resid + 4 * eps * boxes[i].vmax + 0.01 * cell;
-                }
-                else
-                    delta[i] = sphere_delta(i, R);
-                if (boxes[i].candidate && !(ext[i] > large * cell || boxes[i].r < cell / 50)) {
-                    typical.push_back(delta[i]);
-                    r_max = std::max(r_max, 0.87 * ext[i]); // half diagonal of its box at most
-                    if (std::isfinite(delta[i])) d_top_max = std::max(d_top_max, delta[i]);
-                }
-            }
-            if (typical.size() < 32) continue;
-            std::nth_element(typical.begin(), typical.begin() + typical.size() / 2, typical.end());
-            levels = 1;
-            if (typical[typical.size() / 2] > 0.1 * cell) {
-                // Distance levels: D_0 < D_1 < ... < D_top = R, a factor 4 apart; a box is entered into a cell at the
-                // lowest level whose inflation reaches the cell, and the walk reads a cell's entries up to the level
-                // that covers the distance the ray has then come (GridRec::level_dist).
-                margin = r_max + d_top_max + 0.01 * cell;
-                double D0 = 2 * margin + 8 * cell;
-                if (D0 * 64 < R) D0 = R / 64;
-                levels = 1;
-                while (levels < 4 && D0 * std::pow(4.0, levels - 1) < R) ++levels;
-                for (int l = 0; l < levels; ++l) level_D[l] = l == levels - 1 ? R : D0 * std::pow(4.0, l);
-                if (levels == 1 || !(level_D[0] > 1.5 * margin)) levels = 1;
-            }
-            always.clear();
-            std::vector<double> infl;
-            rho_max = 0;
-            double entries = 0;
-            for (size_t i = 0; i < boxes.size(); ++i) {
-                delta0[i] = (levels > 1 && !boxes[i].is_tri) ? sphere_delta(i, level_D[0]) : delta[i];
-                bool grid_it;
-                if (boxes[i].is_tri) {
                     grid_it = boxes[i].candidate && !(ext[i] > large * cell) && !(delta[i] > 0.5 * cell) && std::isfinite(delta[i]);
-                    if (grid_it) rho_max = std::max(rho_max, 16 * eps * std::sqrt(kGridDir2Max) * boxes[i].e1e2 / 1e-7);
+                    if (grid_it) rho_max = std::max(rho_max, rho);
                 }
-                else
-                    grid_it = !(ext[i] > large * cell || boxes[i].r < cell / 50 || delta0[i] > 0.5 * cell);
-                if (grid_it) {
-                    infl.push_back(delta0[i]);
-                    double n = 1;
-                    for (int k = 0; k < 3; ++k) n *= std::floor((boxes[i].hi[k] - boxes[i].lo[k] + 2 * delta[i]) / cell) + 2;
-                    entries += n;
+                else {
+                    const double r = boxes[i].r, m = 32 * eps * (R * R + r * r);
+                    delta[i] = std::sqrt(r * r + m) - r + 0.01 * cell; // the test can succeed up to sqrt(r^2 + m) from the centre
+                    grid_it = !(ext[i] > large * cell || boxes[i].r < cell / 50 || delta[i] > 0.5 * cell);
                 }
+                if (grid_it)
+                    infl.push_back(delta[i]);
                 else
                     always.push_back((uint32_t)boxes[i].idx);
             }
-            if (always.size() > 48 || infl.size() < 32 || entries > 3.5e6) continue;
+            if (always.size() > 48 || infl.size() < 32) continue;
             std::nth_element(infl.begin(), infl.begin() + infl.size() / 2, infl.end());
-            if (levels == 1 && mult > 3.0 && infl[infl.size() / 2] > 0.1 * cell) continue; // (one level was forced: no room for more)
+            if (mult > 3.0 && infl[infl.size() / 2] > 0.1 * cell) continue;
             built = true;
             break;
         }
@@ -236,70 +196,56 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
                 if (!is_always[i]) gridded.push_back((int)i);
         }
         for (int k = 0; k < 3; ++k) lo[k] = 1e300, hi[k] = -1e300;
-        double slack_max = 0, lo0[3] = {1e300, 1e300, 1e300}, hi0[3] = {-1e300, -1e300, -1e300};
+        double slack_max = 0;
         for (int i : gridded) {
             slack_max = std::max(slack_max, delta[i]);
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::min(lo[k], boxes[i].lo[k] - delta[i]), hi[k] = std::max(hi[k], boxes[i].hi[k] + delta[i]);
-                lo0[k] = std::min(lo0[k], boxes[i].lo[k] - delta0[i]), hi0[k] = std::max(hi0[k], boxes[i].hi[k] + delta0[i]);
-            }
+            for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], boxes[i].lo[k] - delta[i]), hi[k] = std::max(hi[k], boxes[i].hi[k] + delta[i]);
         }
         int dims[3];
-        double total = 1, cellk[3];
+        double total = 1;
         for (int k = 0; k < 3; ++k) {
-            cellk[k] = cell;
             dims[k] = (int)std::ceil((hi[k] - lo[k]) / cell);
-            // with distance levels the box is much fatter than what a nearby ray sees: an axis along which the
-            // primitives themselves span two cells at most stays ONE layer of tall cells (every layer is a step)
-            if (levels > 1 && hi0[k] - lo0[k] <= 2 * cell) dims[k] = 1, cellk[k] = (hi[k] - lo[k]) * (1 + 1e-9);
             if (dims[k] < 1) dims[k] = 1;
             total *= dims[k];
         }
-        if (total * levels > 1048576.0 || total > 262144.0 || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
+        if (total > 262144.0 || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
             large = large0, cell *= 1.6;
             continue;
         }
         hd = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-        // fill: bucket = (cell, level); cell_start[cell * levels + l] = first entry of level l, and the entries of
-        // the levels <= l end where bucket (cell, l + 1) - or the next cell - begins
+        // fill
         const int ncell = dims[0] * dims[1] * dims[2];
-        const size_t nbucket = (size_t)ncell * levels;
-        std::vector<uint32_t> count(nbucket + 1, 0);
-        auto range = [&](int i, int k, double d, int &a, int &z) {
-            a = (int)std::floor((boxes[i].lo[k] - d - lo[k]) / cellk[k]), z = (int)std::floor((boxes[i].hi[k] + d - lo[k]) / cellk[k]);
+        std::vector<uint32_t> count(ncell + 1, 0);
+        auto range = [&](int i, int k, int &a, int &z) {
+            a = (int)std::floor((boxes[i].lo[k] - delta[i] - lo[k]) / cell), z = (int)std::floor((boxes[i].hi[k] + delta[i] - lo[k]) / cell);
             a = std::max(a, 0), z = std::min(z, dims[k] - 1);
         };
-        auto level_delta = [&](int i, int l) { return (levels == 1 || boxes[i].is_tri || l == levels - 1) ? delta[i] : sphere_delta((size_t)i, level_D[l]); };
         for (int pass = 0; pass < 2; ++pass) {
             for (int i : gridded) {
-                int a[4][3], z[4][3];
-                for (int l = 0; l < levels; ++l)
-                    for (int k = 0; k < 3; ++k) range(i, k, level_delta(i, l), a[l][k], z[l][k]);
-                const int top = levels - 1;
-                for (int iz = a[top][2]; iz <= z[top][2]; ++iz)
-                    for (int iy = a[top][1]; iy <= z[top][1]; ++iy)
-                        for (int ix = a[top][0]; ix <= z[top][0]; ++ix) {
-                            int lev = 0; // the lowest level whose (nested) range holds this cell
-                            while (lev < top && (ix < a[lev][0] || ix > z[lev][0] || iy < a[lev][1] || iy > z[lev][1] || iz < a[lev][2] || iz > z[lev][2])) ++lev;
-                            const size_t b = ((size_t)(iz * dims[1] + iy) * dims[0] + ix) * levels + lev;
+                int a[3], z[3];
+                for (int k = 0; k < 3; ++k) range(i, k, a[k], z[k]);
+                for (int iz = a[2]; iz <= z[2]; ++iz)
+                    for (int iy = a[1]; iy <= z[1]; ++iy)
+                        for (int ix = a[0]; ix <= z[0]; ++ix) {
+                            const int cidx = (iz * dims[1] + iy) * dims[0] + ix;
                             if (pass == 0)
-                                count[b + 1] += 1;
+                                count[cidx + 1] += 1;
                             else
-                                cell_prims[count[b]++] = (uint16_t)boxes[i].idx;
+                                cell_prims[count[cidx]++] = (uint16_t)boxes[i].idx;
                         }
             }
             if (pass == 0) {
-                for (size_t q = 0; q < nbucket; ++q) count[q + 1] += count[q];
+                for (int q = 0; q < ncell; ++q) count[q + 1] += count[q];
                 cell_start.assign(count.begin(), count.end());
-                cell_prims.assign(count[nbucket], 0);
-                if (count[nbucket] > 4000000u) return false;
+                cell_prims.assign(count[ncell], 0);
+                if (count[ncell] > 4000000u) return false;
             }
         }
-        // within a bucket keep primitive order (not needed for correctness; keeps runs deterministic)
-        for (size_t q = 0; q < nbucket; ++q) std::sort(cell_prims.begin() + cell_start[q], cell_prims.begin() + cell_start[q + 1]);
+        // within a cell keep primitive order (not needed for correctness; keeps runs deterministic)
+        for (int q = 0; q < ncell; ++q) std::sort(cell_prims.begin() + cell_start[q], cell_prims.begin() + cell_start[q + 1]);
         for (int k = 0; k < 3; ++k) {
-            G.gmin[k] = (F)lo[k], G.gmax[k] = (F)(lo[k] + dims[k] * cellk[k]);
-            G.cell[k] = (F)cellk[k], G.inv_cell[k] = (F)(1.0 / cellk[k]);
+            G.gmin[k] = (F)lo[k], G.gmax[k] = (F)(lo[k] + dims[k] * cell);
+            G.cell[k] = (F)cell, G.inv_cell[k] = (F)(1.0 / cell);
             G.dims[k] = dims[k];
             G.center[k] = (F)(0.5 * (lo[k] + hi[k]));
         }
@@ -308,12 +254,10 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         G.slack1 = (F)std::max(1.5 * std::sqrt(32 * eps), 8 * rho_max); // times (|o - centre| + half diagonal); 8 rho: a gridded triangle's residual
         G.dir2_max = (F)(rho_max > 0 ? kGridDir2Max : (sizeof(F) == 4 ? 1e15 : 1e120)); // (Limits<F>::coop_big() when no triangle is gridded)
         G.half_diag = (F)hd;
-        G.levels = levels;
-        for (int l = 0; l < 3; ++l) G.level_dist[l] = l + 1 < levels ? (F)std::max(level_D[l] - margin, 0.0) : std::numeric_limits<F>::infinity();
         G.max_steps = dims[0] + dims[1] + dims[2] + 3 + (int)cell_prims.size(); // trips of the walk: a cell step or a primitive test each
         if (getenv("RRTX_DEBUG_GRID"))
-            fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, largest inflation %g, half diagonal %g, far %g, centre %g %g %g, %d level(s) %g %g %g\n", cell, dims[0],
-                    dims[1], dims[2], cell_prims.size(), always.size(), slack_max, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2], levels, level_D[0], level_D[1], level_D[2]);
+            fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, largest inflation %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],
+                    cell_prims.size(), always.size(), slack_max, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2]);
         return true;
     }
     return false;

@@ -494,7 +494,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (ACCEL == 2)
                     r = accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 else
-                    r = accel_closest_hit<F, true>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice); // (tables in HBM; distance levels possible)
+                    r = accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 need_scan = r == kWalkNeedsScan;
                 still_walking = in_walk = r == kWalkGoesOn;
                 if (VERIFY && !need_scan && !still_walking) { // test build of the kernel: the walk must reproduce the full sequential scan
@@ -1061,7 +1061,6 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> hipError
 // bytes of LDS the accelerated variant wants for its tables (0: they stay in HBM)
 template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
 {
-    if (P.grid.levels > 1) return 0; // (the LDS variant is compiled for one level)
     const size_t b = (size_t)P.n_sph_padded * sizeof(SphereHot<F>) + ((size_t)P.n_grid_cells + 1) * 4 + (((size_t)P.n_grid_prims * 2 + 15) & ~(size_t)15);
     return b <= (size_t)kLdsSceneBytes ? b : 0;
 }

@@ -478,7 +478,7 @@ RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path
 // walks is ~12 cells: 31 % lane utilisation measured.  Lanes whose walk is over go on to shade and
 // start their next segment while the long walkers continue.
 enum { kWalkDone = 0, kWalkNeedsScan = 1, kWalkGoesOn = 2 };
-template <typename F, bool MULTI = false, typename PP, typename HotTab, typename CellTab, typename PrimTab> // MULTI: the grid may have distance levels (GridRec::levels > 1)
+template <typename F, typename PP, typename HotTab, typename CellTab, typename PrimTab>
 RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
                                uint32_t &walk_cell, F &walk_t_out, int max_cells)
 {
@@ -548,7 +548,6 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     else
         ci[0] = (int)(walk_cell & 1023u), ci[1] = (int)((walk_cell >> 10) & 1023u), ci[2] = (int)(walk_cell >> 20);
     const F slack_t = (P.grid.slack + reach) * approx_rsqrt(a);
-    const F len_d = MULTI ? a * approx_rsqrt(a) * (F)1.00001 : (F)0; // |d|
     // the DDA's per-axis distances to the next cell boundary (from the cell, not accumulated: a resumed
     // walk must not depend on where it was interrupted)
 #pragma unroll
@@ -558,20 +557,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     // (a single loop whose trips either test a primitive or step a cell was tried: 59.9 vs 52.6 ms)
     for (int step = 0; step < max_cells; ++step) {
         const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
-        uint32_t beg, end;
-        if (MULTI) {
-            // which of the cell's entries: those of the levels whose inflation covers a ray that has come this
-            // far from its origin when it leaves the cell (over-estimated by a hair: a level too many is only a superset)
-            const F t_exit = tmax[0] <= tmax[1] && tmax[0] <= tmax[2] ? tmax[0] : (tmax[1] <= tmax[2] ? tmax[1] : tmax[2]);
-            const F s_out = t_exit * len_d;
-            uint32_t lev = 0;
-#pragma unroll
-            for (int l = 0; l < 3; ++l) lev += (l + 1 < P.grid.levels && s_out > P.grid.level_dist[l]) ? 1u : 0u;
-            const uint32_t base = cell * (uint32_t)P.grid.levels;
-            beg = cell_start[base], end = cell_start[base + lev + 1u];
-        }
-        else
-            beg = cell_start[cell], end = cell_start[cell + 1];
+        const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
         for (uint32_t k = beg; k < end; ++k) test_primitive<F>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend); // (fetching index k + 1 before testing entry k: 42.0 vs 41.1 ms)
         resolve_pending<F>(pend, a, t_min, tri_base_, best);
         // next cell: across the nearest boundary (branch-free: the three axes diverge otherwise)

@@ -45,7 +45,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
         if (grid) {
             if (cell_prims.empty()) cell_prims.push_back(0);
             P.grid = G, P.grid_cell_start = cell_start.data(), P.grid_cell_prims = cell_prims.data(), P.grid_always = always.empty() ? nullptr : always.data();
-            P.n_always = (int)always.size(), P.n_grid_cells = G.dims[0] * G.dims[1] * G.dims[2], P.n_grid_prims = (int)cell_start.back();
+            P.n_always = (int)always.size(), P.n_grid_cells = (int)cell_start.size() - 1, P.n_grid_prims = (int)cell_start.back();
         }
     }
     const F t_min = (F)0.001; // rrt.cpp:32 typing
@@ -75,8 +75,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
                         F t_out = 0;
                         bool resume = false;
                         do { // in slices of RRTX_WALK_SLICE cells, as the kernel walks
-                            r = P.grid.levels > 1 ? accel_closest_hit<F, true>(P, ps.hot.data(), cell_start.data(), cell_prims.data(), path, a, t_min, best, resume, cell, t_out, 4)
-                                                  : accel_closest_hit<F, false>(P, ps.hot.data(), cell_start.data(), cell_prims.data(), path, a, t_min, best, resume, cell, t_out, 4);
+                            r = accel_closest_hit<F>(P, ps.hot.data(), cell_start.data(), cell_prims.data(), path, a, t_min, best, resume, cell, t_out, 4);
                             resume = true;
                         } while (r == kWalkGoesOn);
                         walked += r == kWalkDone;
