@@ -177,6 +177,34 @@ template <typename F> struct ScanType<F, true> {
 // RESUME: a second pass of the accelerated variants over the work units the first pass parked when the
 // queue ran out (lanes take up paths where they were left, densely packed again); results go to
 // tail_rad, nothing is parked again: an accelerated iteration is cheap enough to run paths to their end.
+// The ray of lane `src` against every primitive, by all 64 lanes of the wave: lane l tests primitives l, l + 64, ...
+// with the exact test; a butterfly picks the winner by consider()'s order-independent rule, which is the answer
+// of the sequential scan for any finite ray.  Every lane returns the result.
+template <typename F, typename HotTab> __device__ __forceinline__ HitInfo<F> wave_exact_scan(const KernelParams<F> &P, HotTab hot, const Path<F> &path, int src, int lane, F t_min)
+{
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    Path<F> rp;
+    rp.o = mk<F>(__shfl(path.o.x, src), __shfl(path.o.y, src), __shfl(path.o.z, src));
+    rp.d = mk<F>(__shfl(path.d.x, src), __shfl(path.d.y, src), __shfl(path.d.z, src));
+    rp.tm = __shfl(path.tm, src);
+    rp.atten = mk<F>(0, 0, 0), rp.depth = 0;
+    const F ra = vlen2<F>(rp.d);
+    HitInfo<F> hb = {Limits<F>::inf(), -1};
+    PendingRoot<F> pend = {-1, 0, 0};
+    for (int idx = lane; idx < tri_base + P.n_tri; idx += 64) {
+        if (idx >= P.n_sph && idx < msph_base) continue; // (padding records)
+        test_primitive<F>(P, hot, idx, rp, ra, t_min, hb, pend);
+    }
+    resolve_pending<F>(pend, ra, t_min, tri_base, hb);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const F ot = __shfl_xor(hb.t, off);
+        const int oi = __shfl_xor(hb.idx, off);
+        if (oi >= 0) consider<F>(ot, oi, tri_base, hb);
+    }
+    return hb;
+}
+constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
 template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
@@ -273,6 +301,26 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             queue_over = __builtin_amdgcn_readfirstlane(over) != 0u;
         }
         loop_count += 1;
+        if (ACCEL != 0) {
+            // ---------------- far rays: an exact scan by the whole wave ---------------------------------
+            // A ray from beyond the grid's range that touches its fattened box has to be tested against every
+            // primitive.  One lane doing that alone holds up its wave for N tests (0.3 ms for 40 000 spheres,
+            // and a path that wanders about out there needs one per bounce: the resume pass of such a scene took
+            // longer than the render).  Here, where all 64 lanes are active, the wave takes such rays one at a time:
+            // lane l tests primitives l, l + 64, ... with the exact test, and a butterfly picks the winner
+            // by consider()'s order-independent rule - the answer of the sequential scan.
+            uint64_t waiting = __ballot(in_walk && walk_cell == kCoopWait);
+            while (__builtin_expect(waiting != 0ull, 0)) { // (rare: marked so, for the register allocator to spill in here and not in the loop)
+                const int src = (int)__builtin_ctzll(waiting);
+                waiting &= waiting - 1ull;
+                HitInfo<F> hb;
+                if (ACCEL == 2)
+                    hb = wave_exact_scan<F>(P, hot_lds, path, src, lane, t_min);
+                else
+                    hb = wave_exact_scan<F>(P, P.sph_hot, path, src, lane, t_min);
+                if (lane == src) best = hb, walk_cell = kCoopDone, n_scanned += 1;
+            }
+        }
         // ---------------- task hand-out: wave64 ballot + prefix popcount -------------------------
         uint64_t want = __ballot(need_task);
         while (want != 0ull) {
@@ -491,12 +539,15 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
                 const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.max_steps;
                 int r;
-                if (ACCEL == 2)
+                if (in_walk && walk_cell == kCoopDone)
+                    r = kWalkDone; // a far ray the wave resolved at the top of this iteration: `best` is final
+                else if (ACCEL == 2)
                     r = accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 else
                     r = accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 need_scan = r == kWalkNeedsScan;
-                still_walking = in_walk = r == kWalkGoesOn;
+                if (r == kWalkFarScan) walk_cell = kCoopWait; // (waits, as a walk in progress, for the next top of the loop)
+                still_walking = in_walk = r == kWalkGoesOn || r == kWalkFarScan;
                 if (VERIFY && !need_scan && !still_walking) { // test build of the kernel: the walk must reproduce the full sequential scan
                     HitInfo<F> full;
                     full.t = Limits<F>::inf();

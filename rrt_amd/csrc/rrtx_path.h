@@ -477,7 +477,10 @@ RRTX_DEV void test_primitive(const PP &P, const HotTab &hot, int idx, const Path
 // through the sphere layer are roughly exponential (mean 2.5 cells), and the longest of 64 such
 // walks is ~12 cells: 31 % lane utilisation measured.  Lanes whose walk is over go on to shade and
 // start their next segment while the long walkers continue.
-enum { kWalkDone = 0, kWalkNeedsScan = 1, kWalkGoesOn = 2 };
+// kWalkNeedsScan: a ray the order-independent rule is not proven for - the sequential scan decides.
+// kWalkFarScan: a sane ray from beyond the grid's range that touches its fattened box - every primitive has to be
+// tested exactly, in any order (the render kernel does that with the whole wave, see there).
+enum { kWalkDone = 0, kWalkNeedsScan = 1, kWalkGoesOn = 2, kWalkFarScan = 3 };
 template <typename F, typename PP, typename HotTab, typename CellTab, typename PrimTab>
 RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
                                uint32_t &walk_cell, F &walk_t_out, int max_cells)
@@ -535,7 +538,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
                 miss = true;
         }
         if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return kWalkDone; // (a hair of tolerance on the far side: the slab arithmetic rounds too)
-        if (is_far) return kWalkNeedsScan;
+        if (is_far) return kWalkFarScan;
         if (t_in > best.t + (P.grid.slack + reach) * approx_rsqrt(a)) return kWalkDone;
         // the cell of the entry point
 #pragma unroll

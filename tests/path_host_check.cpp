@@ -212,7 +212,7 @@ template <typename F> static int run(const char *name, int variant, long n_rays,
         uint32_t cell = 0;
         F t_out = 0;
         int r = accel_closest_hit<F>(s.P, s.hot.data(), s.cell_start.data(), s.cell_prims.data(), path, a, t_min, best, false, cell, t_out, s.P.grid.max_steps);
-        if (r == kWalkNeedsScan) {
+        if (r == kWalkNeedsScan || r == kWalkFarScan) {
             scanned += 1;
             continue;
         }

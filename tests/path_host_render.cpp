@@ -80,7 +80,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
                         } while (r == kWalkGoesOn);
                         walked += r == kWalkDone;
                     }
-                    if (r == kWalkNeedsScan) { // hittable_list.h:95-117
+                    if (r == kWalkNeedsScan || r == kWalkFarScan) { // hittable_list.h:95-117
                         best.t = std::numeric_limits<F>::infinity(), best.idx = -1;
                         for (int k = 0; k < P.n_sph; ++k) refine_sphere<F>(ps.hot[k].cx, ps.hot[k].cy, ps.hot[k].cz, ps.hot[k].r2, path, a, t_min, k, best);
                         for (int k = 0; k < P.n_msph; ++k) {
