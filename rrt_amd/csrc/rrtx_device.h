@@ -114,6 +114,7 @@ template <typename F> struct GridRec {
     F slack, slack1, half_diag; // the walk continues slack + slack1 (|o - center| + half_diag) world units beyond the closest hit so far
     int32_t max_steps;   // bound on the trips of the walk (cells stepped through + primitives tested)
     F dir2_max;          // rays with |d|^2 above this take the list scan: the inflation of gridded triangles is proven up to it
+    int32_t walk_slice;  // cells a lane walks per iteration of the render loop before the others get their turn (4 .. 16)
 };
 
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,

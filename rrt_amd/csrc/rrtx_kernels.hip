@@ -166,7 +166,7 @@ template <typename F> struct ScanType<F, true> {
 #define RRTX_ACCEL_POLL_MASK 3u
 #endif
 #ifndef RRTX_WALK_SLICE
-#define RRTX_WALK_SLICE 4 // cells a lane walks per iteration of the render loop (0: to the end); 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms
+#define RRTX_WALK_SLICE 0 // > 0 overrides GridRec::walk_slice, the cells a lane walks per iteration of the render loop (final.txt: 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms)
 #endif
 #ifndef RRTX_ACCEL_WAVES
 #define RRTX_ACCEL_WAVES 6 // waves per SIMD the accelerated fp32 variants are compiled for (80 VGPRs: 43.6 vs 45.5 ms without the limit)
@@ -537,7 +537,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             bool need_scan = true;
             if (ACCEL != 0) {
                 const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
-                const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.max_steps;
+                const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.walk_slice; // (the macro: experiments)
                 int r;
                 if (in_walk && walk_cell == kCoopDone)
                     r = kWalkDone; // a far ray the wave resolved at the top of this iteration: `best` is final
