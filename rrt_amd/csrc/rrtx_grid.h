@@ -260,6 +260,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         G.slack1 = (F)std::max(1.5 * std::sqrt(32 * eps), 8 * rho_max); // times (|o - centre| + half diagonal); 8 rho: a gridded triangle's residual
         G.dir2_max = (F)(rho_max > 0 ? kGridDir2Max : (sizeof(F) == 4 ? 1e15 : 1e120)); // (Limits<F>::coop_big() when no triangle is gridded)
         G.half_diag = (F)hd;
+        G.max_steps = dims[0] + dims[1] + dims[2] + 3 + (int)cell_prims.size(); // trips of the walk: a cell step or a primitive test each
         // slices of the walk: short in a dense grid, where walks are short (final.txt, one layer of 29 x 29 cells: 4 is
         // the measured optimum - 2 / 3 / 6 cost 15 / 6 / 8 % -; 40 000 spheres in one layer: 8.3 ms with 4, 10.3 with
         // 16), long where a ray crosses dozens of empty cells (a 118 x 23 x 115 mesh grid, 75 % of it empty: 23.6 ms
