@@ -1022,55 +1022,116 @@ template <typename F> __global__ void __launch_bounds__(256) tail_sum_kernel(con
 // order; more (or kappa >= 0.9, or a degenerate camera) marks the pixel 0xFFFF = always scan.
 // Double arithmetic for both precisions: this runs once per scene.
 // ---------------------------------------------------------------------------------------------
+// The conservative test behind the lists: can a ray of the bundle around direction D (camera origin -> a point of
+// the focus plane; the bundle's points there lie within `rho` of D's, its lens offsets within Rl) touch sphere
+// (w = centre - camera origin, radius r)?  dd = |D|^2, inv_cos = 1 / sqrt(1 - ((Rl + rho) / |D|)^2).
+__device__ __forceinline__ bool bundle_may_hit(const double w[3], double r, const double D[3], double dd, double rho, double Rl, double inv_cos)
+{
+    const double w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double wd = w[0] * D[0] + w[1] * D[1] + w[2] * D[2];
+    const double xs = wd / dd; // parameter of the foot point
+    double perp2 = w2 - wd * wd / dd;
+    if (perp2 < 0.0) perp2 = 0.0;
+    const double dev = fabs(1.0 - xs) * Rl + fabs(xs) * rho;
+    const double reach = (fabs(r) + dev) * inv_cos * 1.001 + 1e-5 * (sqrt(w2) + fabs(r));
+    return !(perp2 > reach * reach); // (NaN-safe: anything strange is listed)
+}
+// One block per strip of up to 256 pixels of a row.  Phase A: the block tests every sphere once against the
+// bundle of the whole strip (the same test with the strip's footprint for rho) and compacts the survivors, in
+// primitive order, into LDS; phase B: every pixel tests only those against its own bundle.  (The per-pixel loop
+// over all spheres this replaces cost 1.2 ms per scene on final.txt and 88 ms for 40 000 spheres - more than the
+// frame.)  A strip whose list does not fit falls back to that loop.
+constexpr int kStripList = 4096;
 template <typename F> __global__ void __launch_bounds__(256) primary_lists_kernel(const KernelParams<F> P, uint16_t *plist)
 {
-    const uint32_t n_pixels = (uint32_t)P.local_rows * (uint32_t)P.W;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pixels; q += gridDim.x * blockDim.x) {
-        const uint32_t lr = q / (uint32_t)P.W;
-        const int i = (int)(q - lr * (uint32_t)P.W);
-        const uint32_t tile = lr / (uint32_t)P.tile_rows;
-        const int j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
-        uint16_t *out = plist + (size_t)q * kPlistStride;
-        const double s0 = ((double)i + 0.5) / (double)(P.W - 1), t0 = ((double)j + 0.5) / (double)(P.H - 1);
-        double D[3], len_h = 0, len_v = 0, dd = 0;
+    __shared__ uint16_t strip_list[kStripList];
+    __shared__ uint32_t wave_count[4];
+    __shared__ uint32_t strip_total;
+    const int strips_per_row = (P.W + 255) / 256;
+    const uint32_t lr = blockIdx.x / (uint32_t)strips_per_row;
+    const int i0 = (int)(blockIdx.x % (uint32_t)strips_per_row) * 256;
+    const int n_in = P.W - i0 < 256 ? P.W - i0 : 256;
+    const uint32_t tile = lr / (uint32_t)P.tile_rows;
+    const int j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double len_h = 0, len_v = 0;
+    for (int k = 0; k < 3; ++k) len_h += (double)P.cam.horizontal[k] * (double)P.cam.horizontal[k], len_v += (double)P.cam.vertical[k] * (double)P.cam.vertical[k];
+    const double px_h = sqrt(len_h) / (double)(P.W - 1), px_v = sqrt(len_v) / (double)(P.H - 1); // a pixel's size on the focus plane
+    const double Rl = fabs((double)P.cam.lens_radius);
+    const double t0 = ((double)j + 0.5) / (double)(P.H - 1);
+    auto direction = [&](double ic, double D[3], double &dd) {
+        const double s0 = (ic + 0.5) / (double)(P.W - 1);
+        dd = 0;
         for (int k = 0; k < 3; ++k) {
             D[k] = (double)P.cam.llc[k] + s0 * (double)P.cam.horizontal[k] + t0 * (double)P.cam.vertical[k] - (double)P.cam.origin[k];
             dd += D[k] * D[k];
-            len_h += (double)P.cam.horizontal[k] * (double)P.cam.horizontal[k];
-            len_v += (double)P.cam.vertical[k] * (double)P.cam.vertical[k];
         }
-        const double dist = sqrt(dd);
-        const double rho = 0.5 * sqrt(len_h) / (double)(P.W - 1) + 0.5 * sqrt(len_v) / (double)(P.H - 1);
-        const double Rl = fabs((double)P.cam.lens_radius);
-        const double kappa = (Rl + rho) / dist;
-        if (!(dist > 0.0) || !(kappa < 0.9) || !(dd < 1e300)) { // also catches NaN
-            out[0] = 0xFFFFu;
-            continue;
-        }
-        const double inv_cos = 1.0 / sqrt(1.0 - kappa * kappa);
-        uint32_t count = 0;
-        bool overflow = false;
-        for (int k = 0; k < P.n_sph; ++k) {
-            const SphereHot<F> g = P.sph_hot[k];
-            const double r = (double)P.sph_cold[k].radius;
-            const double wx = (double)g.cx - (double)P.cam.origin[0], wy = (double)g.cy - (double)P.cam.origin[1], wz = (double)g.cz - (double)P.cam.origin[2];
-            const double w2 = wx * wx + wy * wy + wz * wz;
-            const double wd = wx * D[0] + wy * D[1] + wz * D[2];
-            const double xs = wd / dd;                     // parameter of the foot point
-            double perp2 = w2 - wd * wd / dd;
-            if (perp2 < 0.0) perp2 = 0.0;
-            const double dev = fabs(1.0 - xs) * Rl + fabs(xs) * rho;
-            const double reach = (fabs(r) + dev) * inv_cos * 1.001 + 1e-5 * (sqrt(w2) + fabs(r));
-            if (!(perp2 > reach * reach)) { // (NaN-safe: anything strange is listed)
-                if (count < (uint32_t)kPlistCap)
-                    out[1 + count] = (uint16_t)k;
-                else
-                    overflow = true;
-                count += 1;
+    };
+    // ---- phase A: the strip's bundle
+    bool strip_ok;
+    {
+        double D[3], dd;
+        direction((double)i0 + 0.5 * (double)(n_in - 1), D, dd);
+        const double dist = sqrt(dd), rho = 0.5 * (double)n_in * px_h + 0.5 * px_v, kappa = (Rl + rho) / dist;
+        strip_ok = dist > 0.0 && kappa < 0.9 && dd < 1e300; // (block-uniform; also catches NaN)
+        if (threadIdx.x == 0) strip_total = 0;
+        __syncthreads();
+        if (strip_ok) {
+            const double inv_cos = 1.0 / sqrt(1.0 - kappa * kappa);
+            for (int base = 0; base < P.n_sph; base += 256) {
+                const int k = base + (int)threadIdx.x;
+                bool hit = false;
+                if (k < P.n_sph) {
+                    const SphereHot<F> g = P.sph_hot[k];
+                    const double w[3] = {(double)g.cx - (double)P.cam.origin[0], (double)g.cy - (double)P.cam.origin[1], (double)g.cz - (double)P.cam.origin[2]};
+                    hit = bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos);
+                }
+                const uint64_t m = __ballot(hit);
+                if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t offset = strip_total;
+                for (int q = 0; q < wave; ++q) offset += wave_count[q];
+                const uint32_t total = strip_total + wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+                if (hit) {
+                    const uint32_t slot = offset + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (slot < (uint32_t)kStripList) strip_list[slot] = (uint16_t)k;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) strip_total = total;
+                __syncthreads();
             }
         }
-        out[0] = overflow ? (uint16_t)0xFFFFu : (uint16_t)count;
     }
+    const uint32_t n_list = strip_total;
+    const bool use_list = strip_ok && n_list <= (uint32_t)kStripList;
+    // ---- phase B: every pixel's own bundle
+    if ((int)threadIdx.x >= n_in) return;
+    const int i = i0 + (int)threadIdx.x;
+    uint16_t *out = plist + ((size_t)lr * (size_t)P.W + (size_t)i) * kPlistStride;
+    double D[3], dd;
+    direction((double)i, D, dd);
+    const double dist = sqrt(dd), rho = 0.5 * px_h + 0.5 * px_v, kappa = (Rl + rho) / dist;
+    if (!(dist > 0.0) || !(kappa < 0.9) || !(dd < 1e300)) { // also catches NaN
+        out[0] = 0xFFFFu;
+        return;
+    }
+    const double inv_cos = 1.0 / sqrt(1.0 - kappa * kappa);
+    uint32_t count = 0;
+    bool overflow = false;
+    const int n_loop = use_list ? (int)n_list : P.n_sph;
+    for (int q = 0; q < n_loop; ++q) {
+        const int k = use_list ? (int)strip_list[q] : q;
+        const SphereHot<F> g = P.sph_hot[k];
+        const double w[3] = {(double)g.cx - (double)P.cam.origin[0], (double)g.cy - (double)P.cam.origin[1], (double)g.cz - (double)P.cam.origin[2]};
+        if (bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos)) {
+            if (count < (uint32_t)kPlistCap)
+                out[1 + count] = (uint16_t)k;
+            else
+                overflow = true;
+            count += 1;
+        }
+    }
+    out[0] = overflow ? (uint16_t)0xFFFFu : (uint16_t)count;
 }
 
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
@@ -1134,10 +1195,8 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
 }
 template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, uint16_t *plist, hipStream_t stream)
 {
-    const uint32_t n = (uint32_t)P.local_rows * (uint32_t)P.W;
-    int blocks = (int)((n + 255u) / 256u);
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
+    const uint32_t blocks = (uint32_t)P.local_rows * (uint32_t)((P.W + 255) / 256); // one per strip of a row
+    if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(primary_lists_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, plist);
     return hipGetLastError();
 }
