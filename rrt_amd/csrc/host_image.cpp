@@ -174,17 +174,26 @@ int rrtx_write_png(const char *path, const uint8_t *rgb, int w, int h)
             row[0] = 0;
             std::memcpy(row + 1, rgb + (size_t)y * w * 3, (size_t)w * 3);
         }
-        z_stream zs;
-        std::memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;
+        // A path-traced frame is noise on top of the picture: string matching finds nothing in it and costs three
+        // quarters of deflate's time, Huffman coding alone gets the same 0.85 (measured on 1280 x 720: 105 ms and
+        // 0.848 with the default strategy, 31 ms and 0.845 with Z_RLE).  So: run-length + Huffman first, and only
+        // a band that turns out to be compressible (a converged or flat image) is done again with matching, which
+        // is quick on such data.
         std::vector<uint8_t> &out = zb[(size_t)b];
-        out.resize(deflateBound(&zs, (uLong)raw.size()) + 64);
-        zs.next_in = raw.data(), zs.avail_in = (uInt)raw.size();
-        zs.next_out = out.data(), zs.avail_out = (uInt)out.size();
-        const int rc = deflate(&zs, b == bands - 1 ? Z_FINISH : Z_FULL_FLUSH);
-        const bool fine = (b == bands - 1 ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0;
-        out.resize(out.size() - zs.avail_out);
-        deflateEnd(&zs);
+        bool fine = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, attempt == 0 ? Z_RLE : Z_DEFAULT_STRATEGY) != Z_OK) return;
+            out.resize(deflateBound(&zs, (uLong)raw.size()) + 64);
+            zs.next_in = raw.data(), zs.avail_in = (uInt)raw.size();
+            zs.next_out = out.data(), zs.avail_out = (uInt)out.size();
+            const int rc = deflate(&zs, b == bands - 1 ? Z_FINISH : Z_FULL_FLUSH);
+            fine = (b == bands - 1 ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0;
+            out.resize(out.size() - zs.avail_out);
+            deflateEnd(&zs);
+            if (!fine || out.size() * 10 > raw.size() * 6) break; // not below 0.6: matching would not help
+        }
         adler[(size_t)b] = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
         raw_len[(size_t)b] = raw.size();
         ok_band[(size_t)b] = fine ? 1 : 0;
