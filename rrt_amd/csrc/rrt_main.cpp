@@ -180,8 +180,12 @@ int main(int argc, char *argv[])
         rc = rrtx_set_scene(ctx, &desc);
         if (rc) die_device(rc);
 
-        // (owned by the writer task afterwards)
-        auto fb = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+        // two frame buffers, used in turn: one is being quantised and encoded by the writer task while the next
+        // scene renders into the other (allocating and zero-filling 11 MB per frame cost more than a short render)
+        static std::shared_ptr<std::vector<fp_t>> frames[2];
+        std::shared_ptr<std::vector<fp_t>> &slot = frames[job & 1];
+        if (!slot) slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+        auto fb = slot;
         // rrt.cu:195-202,261
         std::cerr << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
         std::cerr << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
