@@ -197,6 +197,11 @@ const char *rrtx_last_error(void);
 int rrtx_device_count(void);                       /* main.cpp:17 cudaGetDeviceCount        */
 int rrtx_query(int device, rrtx_devinfo *out);     /* main.cpp:19 cudaGetDeviceProperties   */
 int rrtx_runtime_version(void);                    /* rrt.cu:195 cudaRuntimeGetVersion      */
+/* Optional: page-lock a caller-owned frame buffer so that rrtx_render's copy-back runs at link speed (the
+ * reference returns managed memory, rrt.cu:204; a pageable 11 MB frame costs ~1.5 ms more per render).
+ * rrtx_unpin_host before the memory is freed.  Both are no-ops returning RRTX_OK on NULL / 0 bytes. */
+int rrtx_pin_host(void *ptr, size_t bytes);
+int rrtx_unpin_host(void *ptr);
 
 /* Rrt::Rrt (rrt.h:16-31). */
 int rrtx_create(const rrtx_params *params, rrtx_ctx **out);

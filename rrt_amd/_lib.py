@@ -126,6 +126,8 @@ _sig("rrtx_last_error", C.c_char_p, [])
 _sig("rrtx_device_count", C.c_int, [])
 _sig("rrtx_query", C.c_int, [C.c_int, C.POINTER(DevInfo)])
 _sig("rrtx_runtime_version", C.c_int, [])
+_sig("rrtx_pin_host", C.c_int, [C.c_void_p, C.c_size_t])
+_sig("rrtx_unpin_host", C.c_int, [C.c_void_p])
 _sig("rrtx_create", C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)])
 _sig("rrtx_destroy", None, [C.c_void_p])
 _sig("rrtx_set_scene", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)])

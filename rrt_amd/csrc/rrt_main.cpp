@@ -142,6 +142,7 @@ int main(int argc, char *argv[])
     }
 
     rrtx_ctx *ctx = nullptr;
+    std::shared_ptr<std::vector<fp_t>> frames[2]; // page-locked once, used in turn (see below)
     std::future<int> writer; // the previous scene's quantise + encode, running beside this scene's render
     int exit_code = 0;
     for (size_t job = 0; job < scene_files.size(); ++job) {
@@ -151,6 +152,8 @@ int main(int argc, char *argv[])
         int rc = rrtx_scene_load(scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
         if (rc) {
             if (writer.valid()) writer.get();
+            for (auto &f : frames)
+                if (f) (void)rrtx_unpin_host(f->data());
             int code = rrtx_scene_exit_code();
             return code ? code : 1;
         }
@@ -182,9 +185,11 @@ int main(int argc, char *argv[])
 
         // two frame buffers, used in turn: one is being quantised and encoded by the writer task while the next
         // scene renders into the other (allocating and zero-filling 11 MB per frame cost more than a short render)
-        static std::shared_ptr<std::vector<fp_t>> frames[2];
         std::shared_ptr<std::vector<fp_t>> &slot = frames[job & 1];
-        if (!slot) slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+        if (!slot) {
+            slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+            (void)rrtx_pin_host(slot->data(), slot->size() * sizeof(fp_t)); // (best effort: unpinned it is only slower)
+        }
         auto fb = slot;
         // rrt.cu:195-202,261
         std::cerr << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
@@ -225,6 +230,8 @@ int main(int argc, char *argv[])
         });
     }
     if (writer.valid() && writer.get()) exit_code = 1;
+    for (auto &f : frames)
+        if (f) (void)rrtx_unpin_host(f->data());
     if (ctx) rrtx_destroy(ctx);
     return exit_code;
 }

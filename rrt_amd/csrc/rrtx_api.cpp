@@ -265,6 +265,20 @@ int rrtx_runtime_version(void)
     return v;
 }
 
+int rrtx_pin_host(void *ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0) return RRTX_OK;
+    RRTX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return RRTX_OK;
+}
+
+int rrtx_unpin_host(void *ptr)
+{
+    if (!ptr) return RRTX_OK;
+    RRTX_HIP(hipHostUnregister(ptr));
+    return RRTX_OK;
+}
+
 int rrtx_query(int device, rrtx_devinfo *out)
 {
     if (!out) return fail(RRTX_E_INVALID, "rrtx_query: null output");
