@@ -126,7 +126,15 @@ int main(int argc, char *argv[])
                 usage(argv[i]);
             break;
         case 'q': query_devices(); break;
-        case 'D': prm.device = atoi(next()); break;
+        case 'D': {
+            // main.cpp:107-110 selects the device while parsing (cudaSetDevice, fatal on a bad ordinal): the same
+            // here - a bad ordinal ends the run with code 99 before any scene is read
+            prm.device = atoi(next());
+            rrtx_devinfo probe;
+            int rc = rrtx_query(prm.device, &probe);
+            if (rc) die_device(rc);
+            break;
+        }
         case 'C': prm.sample_chunk = atoi(next()); break;
         case 'S': prm.seed = (uint32_t)strtoul(next(), nullptr, 10); break;
         case 'R': prm.shard_rank = atoi(next()); break;

@@ -230,6 +230,20 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     return P;
 }
 
+// Everything rrtx_set_scene allocates (tables, grid, camera-ray lists, parked-item buffers).
+void free_scene_buffers(rrtx_ctx *c)
+{
+    void **bufs[] = {&c->d_hot, &c->d_filter, &c->d_cold, &c->d_msph, &c->d_tri, &c->d_tri_scan, &c->d_mat, (void **)&c->d_grid_cell_start, (void **)&c->d_grid_cell_prims,
+                     (void **)&c->d_grid_always, (void **)&c->d_plist, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
+    for (void **b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    c->have_scene = false;
+    c->accel = false;
+    c->tail_capacity = 0;
+}
+
 int drain_events(rrtx_ctx *c, double *last_ms)
 {
     for (int i = 0; i < c->ev_pending; ++i) {
@@ -399,9 +413,26 @@ void rrtx_destroy(rrtx_ctx *c)
     delete c;
 }
 
+static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s);
+
 int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
 {
     if (!c || !s) return fail(RRTX_E_INVALID, "rrtx_set_scene: null argument");
+    const int rc = set_scene_impl(c, s);
+    if (rc != RRTX_OK) {
+        // a scene that did not make it leaves the context without one - and without its buffers: every
+        // device allocation of the attempt is owned by the context as soon as it exists, so this frees
+        // them all (g_error keeps the first failure's message)
+        const std::string keep = g_error;
+        (void)hipSetDevice(c->device);
+        free_scene_buffers(c);
+        g_error = keep;
+    }
+    return rc;
+}
+
+static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
+{
     if ((s->fp64 != 0) != (c->p.fp64 != 0)) return fail(RRTX_E_INVALID, "rrtx_set_scene: scene precision differs from the context's");
     if (!s->camera) return fail(RRTX_E_INVALID, "rrtx_set_scene: no camera");
     if (s->num_materials < 1 || !s->materials) return fail(RRTX_E_INVALID, "rrtx_set_scene: no materials");
@@ -434,6 +465,7 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         const size_t bytes = (size_t)c->local_rows * c->p.image_width * kPlistStride * sizeof(uint16_t);
         uint16_t *pl = nullptr;
         RRTX_HIP(hipMalloc((void **)&pl, bytes));
+        c->d_plist = pl; // owned by the context from here on: a failing launch below must not leak it
         if (c->p.fp64) {
             KernelParams<double> P = make_params<double>(c, nullptr);
             RRTX_HIP(launch_primary_lists<double>(P, pl, c->stream));
@@ -443,7 +475,6 @@ int rrtx_set_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             RRTX_HIP(launch_primary_lists<float>(P, pl, c->stream));
         }
         RRTX_HIP(hipStreamSynchronize(c->stream));
-        c->d_plist = pl;
     }
     // parked-item buffer: every resident wave can park at most kHandoffLanes items
     if (c->d_tail_items) {
@@ -587,11 +618,18 @@ int rrtx_render(rrtx_ctx *c, void *fb, rrtx_stats *stats)
     auto t1 = std::chrono::steady_clock::now();
     c->last_wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (bytes) {
-        std::vector<unsigned char> host(bytes);
-        RRTX_HIP(hipMemcpy(host.data(), c->d_rows, bytes, hipMemcpyDeviceToHost));
+        // straight into the caller's frame (DMA at link speed when it is page-locked, rrtx_pin_host): the
+        // whole block when the shard is the frame, else run by run of consecutive rows (a tile, or several
+        // tiles that happen to touch)
         std::vector<int32_t> rows;
         rows_of_shard(c->p, &rows);
-        for (size_t k = 0; k < rows.size(); ++k) memcpy((unsigned char *)fb + (size_t)rows[k] * row_bytes, host.data() + k * row_bytes, row_bytes);
+        for (size_t k = 0; k < rows.size();) {
+            size_t e = k + 1;
+            while (e < rows.size() && rows[e] == rows[e - 1] + 1) ++e;
+            RRTX_HIP(hipMemcpyAsync((unsigned char *)fb + (size_t)rows[k] * row_bytes, (const unsigned char *)c->d_rows + k * row_bytes, (e - k) * row_bytes, hipMemcpyDeviceToHost, c->stream));
+            k = e;
+        }
+        RRTX_HIP(hipStreamSynchronize(c->stream));
     }
     return rrtx_collect(c, stats);
 }

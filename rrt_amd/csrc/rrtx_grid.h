@@ -18,6 +18,18 @@
 
 namespace rrtx {
 
+// Tuning knobs read from the environment exist in experiment builds only (-DRRTX_EXPERIMENTS): a stray
+// variable must not change the grid of the shipped drop-in.
+inline double grid_knob(const char *name, double dflt)
+{
+#ifdef RRTX_EXPERIMENTS
+    if (const char *v = getenv(name)) return atof(v);
+#else
+    (void)name;
+#endif
+    return dflt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Acceleration grid for use_bvh != 0 (device side: accel_closest_hit).
 //
@@ -120,10 +132,10 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
     }
     if (sorted.size() < 32) return false; // nothing to gain on a handful of primitives
     std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-    double cell = (getenv("RRTX_GRID_CELL") ? atof(getenv("RRTX_GRID_CELL")) : 2.0) * sorted[sorted.size() / 2]; // (the environment overrides are for experiments)
+    double cell = grid_knob("RRTX_GRID_CELL", 2.0) * sorted[sorted.size() / 2];
     if (!(cell > 0) || !std::isfinite(cell)) return false;
 
-    const double large0 = getenv("RRTX_GRID_LARGE") ? atof(getenv("RRTX_GRID_LARGE")) : 1.6;
+    const double large0 = grid_knob("RRTX_GRID_LARGE", 1.6);
     double large = large0;
     const double eps = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
     const double cam_o[3] = {(double)cam.origin[0], (double)cam.origin[1], (double)cam.origin[2]};
@@ -214,7 +226,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         }
         // (2 M cells = 8 MB of cell_start: with 262 144 a mesh of 27 k triangles had to make do with cells of 0.14
         // instead of 0.087, 31.7 against 22.3 ms)
-        if (total > (getenv("RRTX_GRID_MAXCELLS") ? atof(getenv("RRTX_GRID_MAXCELLS")) : 2097152.0) || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
+        if (total > grid_knob("RRTX_GRID_MAXCELLS", 2097152.0) || dims[0] > 1023 || dims[1] > 1023 || dims[2] > 1023) { // (the kernel packs a cell's coordinates into 3 x 10 bits)
             large = large0, cell *= 1.6;
             continue;
         }
@@ -271,7 +283,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             for (int q = 0; q < ncell; ++q) empty += cell_start[q + 1] == cell_start[q];
             G.walk_slice = RRTX_GRID_SLICE_OVERRIDE > 0 ? RRTX_GRID_SLICE_OVERRIDE : (2 * empty > (size_t)ncell && dims[0] + dims[1] + dims[2] >= 128 ? 16 : 4);
         }
-        if (getenv("RRTX_DEBUG_GRID"))
+        if (grid_knob("RRTX_DEBUG_GRID", 0.0) != 0.0)
             fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, largest inflation %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],
                     cell_prims.size(), always.size(), slack_max, hd, far, (double)G.center[0], (double)G.center[1], (double)G.center[2]);
         return true;

@@ -1025,7 +1025,12 @@ template <typename F> __global__ void __launch_bounds__(256) tail_sum_kernel(con
 // The conservative test behind the lists: can a ray of the bundle around direction D (camera origin -> a point of
 // the focus plane; the bundle's points there lie within `rho` of D's, its lens offsets within Rl) touch sphere
 // (w = centre - camera origin, radius r)?  dd = |D|^2, inv_cos = 1 / sqrt(1 - ((Rl + rho) / |D|)^2).
-__device__ __forceinline__ bool bundle_may_hit(const double w[3], double r, const double D[3], double dd, double rho, double Rl, double inv_cos)
+// `eps` is the unit roundoff of the precision the rays are traced in: the reference's discriminant, evaluated in that
+// precision, can be >= 0 for a line that MISSES the sphere - by up to sqrt(r^2 + m) - r with m = 32 eps (|oc|^2 + r^2)
+// (the bound build_grid inflates its boxes by; rrtx_grid.h) - and a pixel's list must hold every sphere the sequential
+// scan would report, not only those geometry says can be hit.  For a small sphere far away that term, which grows
+// with the SQUARE of the distance, dwarfs any relative slack: r = 0.2 at 200 units in fp32 "hits" up to 0.4 away.
+__device__ __forceinline__ bool bundle_may_hit(const double w[3], double r, const double D[3], double dd, double rho, double Rl, double inv_cos, double eps)
 {
     const double w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     const double wd = w[0] * D[0] + w[1] * D[1] + w[2] * D[2];
@@ -1033,7 +1038,9 @@ __device__ __forceinline__ bool bundle_may_hit(const double w[3], double r, cons
     double perp2 = w2 - wd * wd / dd;
     if (perp2 < 0.0) perp2 = 0.0;
     const double dev = fabs(1.0 - xs) * Rl + fabs(xs) * rho;
-    const double reach = (fabs(r) + dev) * inv_cos * 1.001 + 1e-5 * (sqrt(w2) + fabs(r));
+    const double oc_max = sqrt(w2) + Rl; // |o - c| of any ray of the bundle
+    const double r_eff = sqrt(r * r + 32.0 * eps * (oc_max * oc_max + r * r));
+    const double reach = (r_eff + dev) * inv_cos * 1.001 + 1e-5 * (sqrt(w2) + fabs(r));
     return !(perp2 > reach * reach); // (NaN-safe: anything strange is listed)
 }
 // One block per strip of up to 256 pixels of a row.  Phase A: the block tests every sphere once against the
@@ -1058,6 +1065,7 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
     for (int k = 0; k < 3; ++k) len_h += (double)P.cam.horizontal[k] * (double)P.cam.horizontal[k], len_v += (double)P.cam.vertical[k] * (double)P.cam.vertical[k];
     const double px_h = sqrt(len_h) / (double)(P.W - 1), px_v = sqrt(len_v) / (double)(P.H - 1); // a pixel's size on the focus plane
     const double Rl = fabs((double)P.cam.lens_radius);
+    const double eps_f = sizeof(F) == 4 ? 0x1p-24 : 0x1p-53;
     const double t0 = ((double)j + 0.5) / (double)(P.H - 1);
     auto direction = [&](double ic, double D[3], double &dd) {
         const double s0 = (ic + 0.5) / (double)(P.W - 1);
@@ -1084,7 +1092,7 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
                 if (k < P.n_sph) {
                     const SphereHot<F> g = P.sph_hot[k];
                     const double w[3] = {(double)g.cx - (double)P.cam.origin[0], (double)g.cy - (double)P.cam.origin[1], (double)g.cz - (double)P.cam.origin[2]};
-                    hit = bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos);
+                    hit = bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos, eps_f);
                 }
                 const uint64_t m = __ballot(hit);
                 if (lane == 0) wave_count[wave] = (uint32_t)__popcll(m);
@@ -1123,7 +1131,7 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
         const int k = use_list ? (int)strip_list[q] : q;
         const SphereHot<F> g = P.sph_hot[k];
         const double w[3] = {(double)g.cx - (double)P.cam.origin[0], (double)g.cy - (double)P.cam.origin[1], (double)g.cz - (double)P.cam.origin[2]};
-        if (bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos)) {
+        if (bundle_may_hit(w, (double)P.sph_cold[k].radius, D, dd, rho, Rl, inv_cos, eps_f)) {
             if (count < (uint32_t)kPlistCap)
                 out[1 + count] = (uint16_t)k;
             else

@@ -132,13 +132,13 @@ def main(argv=None):
 
     from .render import quantise, write_png, write_ppm
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises the HIP runtime: RCCL's IPC needs dmabuf mode
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("RRTX_DIST_BACKEND", "nccl")
     device_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -149,15 +149,20 @@ def main(argv=None):
     st = sr.rrt.collect()
     print("rank %d: %d rows, took %g seconds." % (sr.rank, len(sr.rows), st["kernel_ms"] / 1000.0), file=sys.stderr)
     rc = 0
-    if sr.rank == 0:
-        rgb = quantise(frame.cpu().numpy(), a.spp)
-        if a.png:
-            write_png(a.png, rgb)
-        else:
-            write_ppm(None, rgb)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    try:
+        if sr.rank == 0:
+            rgb = quantise(frame.cpu().numpy(), a.spp)
+            if a.png:
+                write_png(a.png, rgb)
+            else:
+                write_ppm(None, rgb)
+    except Exception as e:  # the other ranks wait in the barrier below: reach it whatever happened here
+        print("rank 0: could not write the image: %r" % (e,), file=sys.stderr)
+        rc = 1
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
     return rc
 
 
