@@ -203,52 +203,7 @@ def test_statistical_agreement_with_the_real_rrtc(gpu):
         assert np.abs(blocks).max() < 1.5, (name, np.abs(blocks).max())
 
 
-# ---- BASELINE.json full sizes: size-independent properties + spot rows against the oracle ----------
-
-
-def test_config2_test1_1200x800_spp10(gpu):
-    w, h, spp = 1200, 800, 10
-    fb, st = _render(gpu, SCENES["test1"], w, h, spp)  # default chunking (8 + 2)
-    assert st["samples"] == w * h * spp and st["sample_chunk"] == 8
-    o = Oracle(SCENES["test1"], w, h, False)
-    for j in (0, 399, 400, 799):  # rows bit-exact against the oracle with the same sum shape
-        fo, _ = o.render(spp, 50, 1984, order=1, chunk=8, rows=(j, j + 1))
-        assert np.array_equal(fb[j], fo[j]), j
-    assert np.isfinite(fb).all() and (fb >= 0).all()
-    # reference sum order differs from the chunked one by rounding only
-    fb_ref, _ = _render(gpu, SCENES["test1"], w, h, spp, sample_chunk=-1)
-    assert np.allclose(fb, fb_ref, rtol=4e-7 * spp, atol=0)
-    assert np.abs(gpu.quantise(fb, spp).astype(int) - gpu.quantise(fb_ref, spp).astype(int)).max() <= 1
-
-
-def test_config3_final_1200x800_rows_and_shard_invariance(gpu):
-    w, h, spp = 1200, 800, 16
-    full, st = _render(gpu, SCENES["final"], w, h, spp)
-    assert 2.4 < st["segments"] / st["samples"] < 2.65  # 2.525 segments/sample in fp32
-    assert st["prim_tests"] == st["segments"] * 488
-    o = Oracle(SCENES["final"], w, h, False)
-    for j in (3, 500):
-        fo, _ = o.render(spp, 50, 1984, order=1, chunk=8, rows=(j, j + 1))
-        assert np.array_equal(full[j], fo[j]), j
-    sc = gpu.Scene(SCENES["final"], w, h)
-    acc = np.zeros_like(full)
-    for rank in range(8):  # the 8-GPU decomposition, executed on one device
-        r = _list_rrt(gpu, w, h, spp, 50, shard_rank=rank, shard_count=8, tile_rows=4)
-        part = r.render(sc)
-        rows = r.shard_rows()
-        acc[rows] = part[rows]
-        r.close()
-    assert np.array_equal(acc, full)
-
-
-def test_config4_final_fp64_rows(gpu):
-    w, h, spp = 1200, 800, 4
-    fb, st = _render(gpu, SCENES["final"], w, h, spp, fp64=True)
-    assert 2.2 < st["segments"] / st["samples"] < 2.45  # fp64: 2.318 segments/sample
-    o = Oracle(SCENES["final"], w, h, True)
-    for j in (10, 640):
-        fo, _ = o.render(spp, 50, 1984, order=1, rows=(j, j + 1))
-        assert np.array_equal(fb[j], fo[j]), j
+# (BASELINE.json's configurations at their stated sizes: tests/test_gpu_configs.py)
 
 
 def test_cli_matches_the_library(gpu, tmp_path):
