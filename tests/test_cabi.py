@@ -90,3 +90,26 @@ def test_product_does_not_reference_the_oracle():
                     assert not re.search(r"^\s*(from|import)\s+\S*oracle", text, flags=re.M), os.path.join(dirpath, f)
     libs = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in libs and "libamdhip64" in libs
+
+
+def test_reference_side_binding_is_compiled_against_the_reference_headers():
+    """oracle/_ref/rrt_dropin = the reference's own main.cpp + oracle/ref_dropin.cpp (class Rrt of rrt.h:14-48 over
+    librrtx.so), built by oracle/Makefile where /root/reference exists: INTEGRATION.md section 1 as a binary.  Here
+    (no GPU): it exists, binds the C ABI's entry points dynamically, and fails like check_cuda without a device;
+    what it renders is compared with `rrt` on the GPU (tests/test_gpu_dropin.py)."""
+    from _oracle import REF_DIR, have_reference
+
+    if not have_reference():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    for exe in ("rrt_dropin", "rrtd_dropin"):
+        path = os.path.join(REF_DIR, exe)
+        assert os.path.exists(path), path
+        undefined = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        for sym in ("rrtx_create", "rrtx_set_scene", "rrtx_render", "rrtx_destroy", "rrtx_last_error"):
+            assert re.search(r"\bU %s\b" % sym, undefined), (exe, sym)
+        assert "librrtx.so" in subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+        r = subprocess.run([path], capture_output=True)
+        assert r.returncode == 1 and b"ERROR: no scene loaded." in r.stderr  # the reference's main.cpp:126-128
+        if rrt_amd.device_count() == 0:
+            r = subprocess.run([path, "-i", os.path.join(ROOT, "scenes", "test1.txt"), "-w", "16", "-h", "16", "-s", "1"], capture_output=True)
+            assert r.returncode == 99 and b"HIP error" in r.stderr and r.stdout == b""
