@@ -15,16 +15,20 @@ KFLAGS    := --offload-arch=$(ARCH) $(DEVFLAGS) -fPIC -std=c++17
 HOSTFLAGS := -O2 -ffp-contract=off -fPIC -std=c++17 -Wall
 
 LIB       := rrt_amd/librrtx.so
-OBJS      := $(CSRC)/rrtx_kernels.o $(CSRC)/rrtx_api.o $(CSRC)/host_scene.o $(CSRC)/host_image.o
+OBJS      := $(CSRC)/rrtx_kernels.o $(CSRC)/rrtx_api.o $(CSRC)/rrtx_group.o $(CSRC)/host_scene.o $(CSRC)/host_image.o
 
 default: $(LIB) rrt rrtd
 
 all: default oracle
 
-$(CSRC)/rrtx_kernels.o: $(CSRC)/rrtx_kernels.hip $(CSRC)/rrtx_device.h $(CSRC)/rrtx_path.h
+$(CSRC)/rrtx_kernels.o: $(CSRC)/rrtx_kernels.hip $(CSRC)/rrtx_device.h $(CSRC)/rrtx_path.h $(CSRC)/rrtx_launch.h
 	$(HIPCC) $(KFLAGS) -c $< -o $@
 
 $(CSRC)/rrtx_api.o: $(CSRC)/rrtx_api.cpp $(CSRC)/rrtx_device.h $(CSRC)/rrtx_grid.h $(CSRC)/rrtx_pack.h $(CSRC)/rrtx_launch.h include/rrtx.h
+	$(HIPCC) $(HOSTFLAGS) -c $< -o $@
+
+# (RCCL: the header only - librccl.so is dlopen()ed by the first rrtx_group_create)
+$(CSRC)/rrtx_group.o: $(CSRC)/rrtx_group.cpp $(CSRC)/rrtx_device.h $(CSRC)/rrtx_launch.h include/rrtx.h
 	$(HIPCC) $(HOSTFLAGS) -c $< -o $@
 
 $(CSRC)/host_scene.o: $(CSRC)/host_scene.cpp include/rrtx.h
@@ -34,7 +38,7 @@ $(CSRC)/host_image.o: $(CSRC)/host_image.cpp include/rrtx.h
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -ldl
 
 # drop-in binaries: `rrt` (float) and `rrtd` (double) — same source, precision chosen by name
 rrt: $(CSRC)/rrt_main.cpp $(LIB) include/rrtx.h

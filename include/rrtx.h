@@ -236,6 +236,52 @@ void *rrtx_stream(rrtx_ctx *ctx);
 /* Waits for the renders enqueued so far and fills `stats` for the last one. */
 int rrtx_collect(rrtx_ctx *ctx, rrtx_stats *stats);
 
+/* ---- one frame over several devices of one node ------------------------------------------
+ * BASELINE.json north_star: "the framebuffer is row-tile-partitioned across the 8 GPUs of one node
+ * with a final RCCL gather over xGMI".  The reference has nothing to cite here: it renders on one
+ * device (main.cpp:107-110 merely calls cudaSetDevice).  A group is ONE process driving N devices
+ * from one host thread: N contexts as above (shard_rank = position in the device list,
+ * shard_count = N, params->tile_rows), one stream per device, one RCCL communicator per device
+ * (ncclCommInitAll, rccl.h:236).  rrtx_group_render() enqueues the N shard renders, then ONE grouped
+ * exchange - every rank ncclSend()s its compact row block to rank 0, which ncclRecv()s them side by
+ * side (rccl.h:700; all seven peers of an MI355X have their own xGMI link to the root, so they
+ * transmit concurrently) - a de-interleave pass on rank 0 puts the rows where they belong, and one
+ * copy brings the frame to the host.  The image is the single-device image, bit for bit, for every
+ * N and tile height (the RNG is keyed by the global pixel index).  librccl.so is loaded on first use
+ * (dlopen): single-device runs never touch it. */
+typedef struct rrtx_group rrtx_group;
+
+/* Several contexts may share a device (the list repeats an ordinal): a REHEARSAL of the N-way
+ * decomposition on fewer GPUs, for tests - RCCL cannot build a communicator over duplicates, the row
+ * blocks then move with device-to-device copies instead.  Rejected without this flag. */
+#define RRTX_GROUP_REHEARSAL 1
+
+typedef struct rrtx_group_stats {
+    int32_t n_devices;
+    int32_t rccl;            /* 1: the row blocks moved through ncclSend / ncclRecv             */
+    double render_ms;        /* slowest device's kernel time (HIP events, as rrtx_stats.kernel_ms) */
+    double device_ms;        /* first launch -> assembled frame on device 0 (events on its stream): render + gather + de-interleave */
+    double gather_ms;        /* device_ms - render_ms: what the exchange and the de-interleave add to the slowest render */
+    double wall_ms;          /* host wall time of the call, copy-back included                  */
+    double kernel_ms[16];    /* per device (first 16)                                           */
+    uint64_t samples, segments, prim_tests, bytes_algorithmic; /* summed over the devices      */
+    uint64_t gathered_bytes; /* bytes that crossed to rank 0 (its own block included)           */
+    int32_t sample_chunk, accel_cells;
+} rrtx_group_stats;
+
+/* params: as for rrtx_create; device / shard_rank / shard_count are ignored (set per member).
+ * devices == NULL: ordinals 0 .. n_devices-1. */
+int rrtx_group_create(const rrtx_params *params, int n_devices, const int32_t *devices, int flags, rrtx_group **out);
+void rrtx_group_destroy(rrtx_group *g);
+int rrtx_group_size(const rrtx_group *g);
+/* The i-th member (borrowed; e.g. for rrtx_shard_rows). */
+rrtx_ctx *rrtx_group_member(rrtx_group *g, int i);
+int rrtx_group_set_scene(rrtx_group *g, const rrtx_scene_desc *scene);
+/* `fb`: the whole frame, as rrtx_render's.  Blocking. */
+int rrtx_group_render(rrtx_group *g, void *fb, rrtx_group_stats *stats);
+/* Same, the frame left on the group's first device (pointer valid until the next render / destroy). */
+int rrtx_group_render_device(rrtx_group *g, void **d_frame, rrtx_group_stats *stats);
+
 /* ---- host side of the seam: scene parser (scene.h:212-452) ----------------------------- */
 typedef struct rrtx_scene rrtx_scene;
 /* Parses `path` for a w x h frame (the camera's aspect ratio comes from them, scene.h:254).

@@ -10,6 +10,6 @@ Everything computes in librrtx.so (hand-written HIP for gfx950); nothing here fa
 Python/CPU arithmetic.
 """
 from ._lib import RrtxError  # noqa: F401
-from .render import Rrt, Scene, device_count, query_device, quantise, write_png, write_ppm  # noqa: F401
+from .render import Rrt, RrtGroup, Scene, device_count, query_device, quantise, write_png, write_ppm  # noqa: F401
 
-__all__ = ["Rrt", "Scene", "RrtxError", "device_count", "query_device", "quantise", "write_png", "write_ppm"]
+__all__ = ["Rrt", "RrtGroup", "Scene", "RrtxError", "device_count", "query_device", "quantise", "write_png", "write_ppm"]

@@ -114,6 +114,33 @@ class DevInfo(C.Structure):  # rrtx_devinfo
     ]
 
 
+class GroupStats(C.Structure):  # rrtx_group_stats
+    _fields_ = [
+        ("n_devices", C.c_int32),
+        ("rccl", C.c_int32),
+        ("render_ms", C.c_double),
+        ("device_ms", C.c_double),
+        ("gather_ms", C.c_double),
+        ("wall_ms", C.c_double),
+        ("kernel_ms", C.c_double * 16),
+        ("samples", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("prim_tests", C.c_uint64),
+        ("bytes_algorithmic", C.c_uint64),
+        ("gathered_bytes", C.c_uint64),
+        ("sample_chunk", C.c_int32),
+        ("accel_cells", C.c_int32),
+    ]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "kernel_ms"}
+        d["kernel_ms"] = list(self.kernel_ms)[: max(1, min(16, self.n_devices))]
+        return d
+
+
+GROUP_REHEARSAL = 1
+
+
 def _sig(name, restype, argtypes):
     f = getattr(lib, name)
     f.restype = restype
@@ -136,6 +163,13 @@ _sig("rrtx_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)])
 _sig("rrtx_render_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p])
 _sig("rrtx_collect", C.c_int, [C.c_void_p, C.POINTER(Stats)])
 _sig("rrtx_stream", C.c_void_p, [C.c_void_p])
+_sig("rrtx_group_create", C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)])
+_sig("rrtx_group_destroy", None, [C.c_void_p])
+_sig("rrtx_group_size", C.c_int, [C.c_void_p])
+_sig("rrtx_group_member", C.c_void_p, [C.c_void_p, C.c_int])
+_sig("rrtx_group_set_scene", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)])
+_sig("rrtx_group_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GroupStats)])
+_sig("rrtx_group_render_device", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GroupStats)])
 _sig("rrtx_scene_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)])
 _sig("rrtx_scene_exit_code", C.c_int, [])
 _sig("rrtx_scene_free", None, [C.c_void_p])

@@ -12,7 +12,16 @@
 //   -C <samples per work item>   (0 = automatic, -1 = one item per pixel: reference sum order)
 //   -S <seed>                    (RNG base seed, default 1984)
 //   -R <rank> -N <count> -T <tile_rows>   render only one row-tile shard of the frame
+//   -G <gpus>                    several devices of the node, one process: a frame is cut into row tiles over them and
+//                                gathered with RCCL (rrtx_group); a batch of >= gpus scenes is dealt out scene by scene
+//   -E                           rehearsal of -G on fewer devices than members (they share what is there)
 #include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <sstream>
+#include <thread>
 
 #include <climits>
 #include <cstdio>
@@ -55,6 +64,9 @@ static void usage(const char *arg)
     std::cerr << "  -C <chunk>          : samples per work item (0 = auto, -1 = whole pixel)\n";
     std::cerr << "  -S <seed>           : random seed (1984)\n";
     std::cerr << "  -R <rank> -N <count> -T <tile_rows> : render one row-tile shard only\n";
+    std::cerr << "  -G <gpus>           : use this many devices, starting at -D: a frame is cut into row tiles (-T) and gathered\n";
+    std::cerr << "                        over RCCL; a batch of at least as many scenes is dealt out scene by scene instead\n";
+    std::cerr << "  -E                  : rehearsal: let the -G members share the devices present (tests)\n";
     std::exit(1);
 }
 
@@ -85,8 +97,225 @@ static void query_devices()
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// jobs and workers
+// ---------------------------------------------------------------------------------------------
+struct Job {
+    std::string scene_file;
+    const char *png_file = nullptr;
+    size_t ppm_index = (size_t)-1; // position among the jobs that print a PPM to stdout (they must come out in order)
+};
+
+struct Shared {
+    const std::vector<Job> *jobs = nullptr;
+    std::atomic<size_t> next_job{0};
+    std::atomic<int> exit_code{0};
+    std::atomic<bool> stop{false};
+    std::mutex log_mu; // a job's stderr lines go out in one piece
+    std::mutex out_mu; // stdout: PPMs in job order
+    std::condition_variable out_cv;
+    size_t next_ppm = 0;
+};
+
+struct Worker {
+    rrtx_params prm;
+    Shared *shared = nullptr;
+    int group_size = 0; // > 1: this worker drives a group of devices (row-tile shards of every frame)
+    bool group_rehearsal = false;
+    std::vector<int32_t> group_devices;
+    rrtx_ctx *ctx = nullptr;
+    rrtx_group *group = nullptr;
+    std::shared_ptr<std::vector<fp_t>> frames[2]; // page-locked once, used in turn
+    std::future<int> writer;                       // the previous scene's quantise + encode, running beside this scene's render
+    size_t rendered = 0;
+
+    void log(const std::string &text)
+    {
+        std::lock_guard<std::mutex> lock(shared->log_mu);
+        std::cerr << text << std::flush;
+    }
+    [[noreturn]] void die(int rc, const std::string &so_far)
+    {
+        // check_cuda, rrt.cu:31-40: fatal.  (_Exit: other workers may be in the middle of a render)
+        {
+            std::lock_guard<std::mutex> lock(shared->log_mu);
+            std::cerr << so_far << "HIP error = " << rc << " : " << rrtx_last_error() << "\n" << std::flush;
+        }
+        std::fflush(stdout);
+        std::_Exit(99);
+    }
+    void finish_writer()
+    {
+        if (writer.valid() && writer.get()) shared->exit_code = 1;
+    }
+
+    void run()
+    {
+        const std::vector<Job> &jobs = *shared->jobs;
+        for (;;) {
+            if (shared->stop) break;
+            const size_t k = shared->next_job.fetch_add(1);
+            if (k >= jobs.size()) break;
+            render_job(jobs[k]);
+        }
+        finish_writer();
+        for (auto &f : frames)
+            if (f) (void)rrtx_unpin_host(f->data());
+        if (ctx) rrtx_destroy(ctx);
+        if (group) rrtx_group_destroy(group);
+    }
+
+    void skip_output_turn(const Job &job)
+    {
+        // a job that will not print its PPM must not hold up the ones behind it
+        if (job.ppm_index == (size_t)-1) return;
+        std::unique_lock<std::mutex> lock(shared->out_mu);
+        shared->out_cv.wait(lock, [&] { return shared->next_ppm == job.ppm_index; });
+        shared->next_ppm += 1;
+        shared->out_cv.notify_all();
+    }
+
+    void render_job(const Job &job)
+    {
+        std::ostringstream err; // this job's stderr chatter
+        rrtx_scene *scene = nullptr;
+        int rc = rrtx_scene_load(job.scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
+        if (rc) {
+            // the reference exits on the spot with scene.h's code (1 obj errors, 2 cannot open, 3 unknown material, 4 sanity);
+            // in a batch: no further scenes are started, what is in flight is written, the first such code is the exit code
+            int code = rrtx_scene_exit_code();
+            int expected = 0;
+            shared->exit_code.compare_exchange_strong(expected, code ? code : 1);
+            shared->stop = true;
+            skip_output_turn(job);
+            return;
+        }
+        int32_t counts[6];
+        rrtx_scene_counts(scene, counts);
+        rrtx_scene_desc desc;
+        rrtx_scene_describe(scene, &desc);
+        // scene.h:443-451
+        err << "read scene file: " << job.scene_file << "\n";
+        err << "material count:  " << counts[0] << "\n";
+        err << "sphere count:    " << counts[1] << "\n";
+        err << "msphere count:   " << counts[2] << "\n";
+        err << "obj count:       " << counts[4] << "\n";
+        err << "obj_inst count:  " << counts[5] << "\n";
+        {
+            const fp_t *cam = (const fp_t *)desc.camera;
+            if (cam[22] != cam[23]) err << "camera time:     " << cam[22] << " - " << cam[23] << "\n";
+        }
+
+        std::time_t render_time = std::time(nullptr);
+        std::tm render_tm;
+        localtime_r(&render_time, &render_tm);
+
+        if (group_size > 1) {
+            if (!group) {
+                rc = rrtx_group_create(&prm, group_size, group_devices.data(), group_rehearsal ? RRTX_GROUP_REHEARSAL : 0, &group);
+                if (rc) die(rc, err.str());
+            }
+            rc = rrtx_group_set_scene(group, &desc);
+        }
+        else {
+            if (!ctx) {
+                rc = rrtx_create(&prm, &ctx);
+                if (rc) die(rc, err.str());
+            }
+            rc = rrtx_set_scene(ctx, &desc);
+        }
+        if (rc) die(rc, err.str());
+
+        // two frame buffers, used in turn: one is being quantised and encoded by the writer task while the next
+        // scene renders into the other (allocating and zero-filling 11 MB per frame cost more than a short render)
+        std::shared_ptr<std::vector<fp_t>> &slot = frames[rendered & 1];
+        rendered += 1;
+        if (!slot) {
+            slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
+            (void)rrtx_pin_host(slot->data(), slot->size() * sizeof(fp_t)); // (best effort: unpinned it is only slower)
+        }
+        // (the writer still in flight works on the OTHER buffer: the one that used this buffer was joined before that one started)
+        auto fb = slot;
+        // rrt.cu:195-202,261
+        err << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
+        err << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
+        err << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
+        err << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
+
+        double seconds = 0, samples = 0, bytes_algorithmic = 0;
+        unsigned long long segments = 0, prim_tests = 0;
+        int blocks = 0, accel_cells = 0;
+        std::string how;
+        if (group_size > 1) {
+            err << "HIP Devices:";
+            for (int d : group_devices) err << " " << d;
+            err << (group_rehearsal ? " (rehearsal: members share devices, no RCCL)" : " (row tiles of " + std::to_string(prm.tile_rows > 0 ? prm.tile_rows : 4) + ", RCCL gather to the first)") << "\n";
+            rrtx_group_stats gs;
+            std::memset(&gs, 0, sizeof gs);
+            rc = rrtx_group_render(group, fb->data(), &gs);
+            if (rc) die(rc, err.str());
+            seconds = gs.device_ms / 1000.0, samples = (double)gs.samples, bytes_algorithmic = (double)gs.bytes_algorithmic;
+            segments = gs.segments, prim_tests = gs.prim_tests, accel_cells = gs.accel_cells;
+            std::ostringstream h;
+            h << group_size << " devices: slowest render " << gs.render_ms / 1000.0 << " s, gather " << gs.gather_ms / 1000.0 << " s (" << gs.gathered_bytes << " bytes" << (gs.rccl ? ", RCCL" : ", copies") << "),";
+            how = h.str();
+        }
+        else {
+            err << "HIP Device: " << prm.device << "\n";
+            rrtx_stats st;
+            std::memset(&st, 0, sizeof st);
+            rc = rrtx_render(ctx, fb->data(), &st);
+            if (rc) die(rc, err.str());
+            seconds = st.kernel_ms / 1000.0, samples = (double)st.samples, bytes_algorithmic = (double)st.bytes_algorithmic;
+            segments = st.segments, prim_tests = st.prim_tests, blocks = st.grid_blocks, accel_cells = st.accel_cells;
+        }
+        err << "took " << seconds << " seconds.\n";
+        char hostname[HOST_NAME_MAX + 1];
+        hostname[0] = 0;
+        gethostname(hostname, sizeof hostname);
+        char when[128];
+        std::strftime(when, sizeof when, "%c %Z,", &render_tm);
+        // rrt.cu:312-315: stats,<date>,<host>,<runtime>,<fp>,w,h,spp,blocks,tx,ty,seconds
+        err << "stats," << when << hostname << ",HIP" << rrtx_runtime_version() << "," << kFpName << "," << prm.image_width << "," << prm.image_height << "," << prm.samples_per_pixel << ","
+            << blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
+        if (seconds > 0)
+            err << "rate," << samples / seconds / 1e6 << " Msamples/s," << how << segments << " segments," << prim_tests << " primitive tests," << bytes_algorithmic / seconds / 1e9
+                << " GB/s algorithmic," << (accel_cells ? "grid of " + std::to_string(accel_cells) + " cells" : std::string("list scan")) << "\n";
+        rrtx_scene_free(scene);
+        log(err.str());
+
+        // main.cpp:140-162: quantise, flip, write - off the render path: it overlaps this worker's next scene
+        finish_writer();
+        const int w = prm.image_width, h = prm.image_height, spp = prm.samples_per_pixel;
+        Shared *sh = shared;
+        const Job *jp = &job;
+        writer = std::async(std::launch::async, [fb, jp, sh, w, h, spp]() -> int {
+            std::vector<uint8_t> rgb((size_t)w * h * 3);
+            rrtx_quantise(fb->data(), kFp64, w, h, spp, rgb.data());
+            int wrc;
+            if (jp->png_file)
+                wrc = rrtx_write_png(jp->png_file, rgb.data(), w, h);
+            else {
+                // stdout is one stream: the PPMs of a batch come out in job order, whoever rendered them
+                std::unique_lock<std::mutex> lock(sh->out_mu);
+                sh->out_cv.wait(lock, [&] { return sh->next_ppm == jp->ppm_index; });
+                wrc = rrtx_write_ppm(nullptr, rgb.data(), w, h);
+                sh->next_ppm += 1;
+                sh->out_cv.notify_all();
+            }
+            if (wrc) {
+                std::lock_guard<std::mutex> lock(sh->log_mu);
+                std::cerr << "ERROR: could not write image\n";
+            }
+            return wrc;
+        });
+    }
+};
+
 int main(int argc, char *argv[])
 {
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // (the hosts of this pool only support dmabuf IPC; RCCL wants it set before the runtime starts)
     rrtx_params prm;
     std::memset(&prm, 0, sizeof prm);
     prm.image_width = 1200;
@@ -102,6 +331,8 @@ int main(int argc, char *argv[])
     prm.collect_stats = 1;
     std::vector<std::string> scene_files;
     std::vector<const char *> png_files;
+    int n_gpus = 1;
+    bool rehearse = false;
 
     for (int i = 1; i < argc; ++i) {
         if (argv[i][0] != '-') usage(argv[i]);
@@ -140,6 +371,8 @@ int main(int argc, char *argv[])
         case 'R': prm.shard_rank = atoi(next()); break;
         case 'N': prm.shard_count = atoi(next()); break;
         case 'T': prm.tile_rows = atoi(next()); break;
+        case 'G': n_gpus = atoi(next()); break;
+        case 'E': rehearse = true; break;
         default: usage(argv[i]);
         }
     }
@@ -149,97 +382,47 @@ int main(int argc, char *argv[])
         return 1;
     }
 
-    rrtx_ctx *ctx = nullptr;
-    std::shared_ptr<std::vector<fp_t>> frames[2]; // page-locked once, used in turn (see below)
-    std::future<int> writer; // the previous scene's quantise + encode, running beside this scene's render
-    int exit_code = 0;
-    for (size_t job = 0; job < scene_files.size(); ++job) {
-        const std::string &scene_file = scene_files[job];
-        const char *png_file = job < png_files.size() ? png_files[job] : nullptr;
-        rrtx_scene *scene = nullptr;
-        int rc = rrtx_scene_load(scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
-        if (rc) {
-            if (writer.valid()) writer.get();
-            for (auto &f : frames)
-                if (f) (void)rrtx_unpin_host(f->data());
-            int code = rrtx_scene_exit_code();
-            return code ? code : 1;
-        }
-        int32_t counts[6];
-        rrtx_scene_counts(scene, counts);
-        rrtx_scene_desc desc;
-        rrtx_scene_describe(scene, &desc);
-        // scene.h:443-451
-        std::cerr << "read scene file: " << scene_file << "\n";
-        std::cerr << "material count:  " << counts[0] << "\n";
-        std::cerr << "sphere count:    " << counts[1] << std::endl;
-        std::cerr << "msphere count:   " << counts[2] << std::endl;
-        std::cerr << "obj count:       " << counts[4] << std::endl;
-        std::cerr << "obj_inst count:  " << counts[5] << std::endl;
-        {
-            const fp_t *cam = (const fp_t *)desc.camera;
-            if (cam[22] != cam[23]) std::cerr << "camera time:     " << cam[22] << " - " << cam[23] << std::endl;
-        }
-
-        std::time_t render_time = std::time(nullptr);
-        std::tm render_tm = *std::localtime(&render_time);
-
-        if (!ctx) {
-            rc = rrtx_create(&prm, &ctx);
-            if (rc) die_device(rc);
-        }
-        rc = rrtx_set_scene(ctx, &desc);
-        if (rc) die_device(rc);
-
-        // two frame buffers, used in turn: one is being quantised and encoded by the writer task while the next
-        // scene renders into the other (allocating and zero-filling 11 MB per frame cost more than a short render)
-        std::shared_ptr<std::vector<fp_t>> &slot = frames[job & 1];
-        if (!slot) {
-            slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
-            (void)rrtx_pin_host(slot->data(), slot->size() * sizeof(fp_t)); // (best effort: unpinned it is only slower)
-        }
-        auto fb = slot;
-        // rrt.cu:195-202,261
-        std::cerr << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
-        std::cerr << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
-        rrtx_stats st;
-        std::memset(&st, 0, sizeof st);
-        std::cerr << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
-        std::cerr << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
-        std::cerr << "HIP Device: " << prm.device << std::endl;
-
-        rc = rrtx_render(ctx, fb->data(), &st);
-        if (rc) die_device(rc);
-
-        const double seconds = st.kernel_ms / 1000.0;
-        std::cerr << "took " << seconds << " seconds.\n";
-        char hostname[HOST_NAME_MAX + 1];
-        hostname[0] = 0;
-        gethostname(hostname, sizeof hostname);
-        char when[128];
-        std::strftime(when, sizeof when, "%c %Z,", &render_tm);
-        // rrt.cu:312-315: stats,<date>,<host>,<runtime>,<fp>,w,h,spp,blocks,tx,ty,seconds
-        std::cerr << "stats," << when << hostname << ",HIP" << rrtx_runtime_version() << "," << kFpName << "," << prm.image_width << "," << prm.image_height << ","
-                  << prm.samples_per_pixel << "," << st.grid_blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
-        if (seconds > 0)
-            std::cerr << "rate," << (double)st.samples / seconds / 1e6 << " Msamples/s," << st.segments << " segments," << st.prim_tests << " primitive tests,"
-                      << (double)st.bytes_algorithmic / seconds / 1e9 << " GB/s algorithmic," << (st.accel_cells ? "grid of " + std::to_string(st.accel_cells) + " cells" : std::string("list scan")) << "\n";
-        rrtx_scene_free(scene);
-
-        // main.cpp:140-162: quantise, flip, write — off the render path: it overlaps the next scene
-        if (writer.valid() && writer.get()) exit_code = 1; // (keeps the outputs in order, PPMs on stdout included)
-        const int w = prm.image_width, h = prm.image_height, spp = prm.samples_per_pixel;
-        writer = std::async(std::launch::async, [fb, png_file, w, h, spp]() -> int {
-            std::vector<uint8_t> rgb((size_t)w * h * 3);
-            rrtx_quantise(fb->data(), kFp64, w, h, spp, rgb.data());
-            const int wrc = png_file == nullptr ? rrtx_write_ppm(nullptr, rgb.data(), w, h) : rrtx_write_png(png_file, rgb.data(), w, h);
-            if (wrc) std::cerr << "ERROR: could not write image\n";
-            return wrc;
-        });
+    // ---- who renders what --------------------------------------------------------------------------
+    // -G 1 (default): one device context, the scenes one after another.
+    // -G n, fewer scenes than GPUs: every frame is cut into row tiles over the n GPUs (rrtx_group: one RCCL gather).
+    // -G n, at least n scenes: the scenes are dealt to n workers, one device each - frame-level parallelism, no
+    //       communication at all (the reference's 261-frame animation job, scenes/final_anim/Makefile).
+    const int available = rrtx_device_count();
+    if (n_gpus < 1) n_gpus = 1;
+    if (n_gpus > 1 && !rehearse && n_gpus > available) {
+        std::cerr << "HIP error = -1 : -G " << n_gpus << " but only " << available << " device(s) present\n";
+        return 99;
     }
-    if (writer.valid() && writer.get()) exit_code = 1;
-    for (auto &f : frames)
-        if (f) (void)rrtx_unpin_host(f->data());
-    if (ctx) rrtx_destroy(ctx);
-    return exit_code;
+    std::vector<Job> jobs;
+    size_t n_ppm = 0;
+    for (size_t k = 0; k < scene_files.size(); ++k) {
+        Job j;
+        j.scene_file = scene_files[k], j.png_file = k < png_files.size() ? png_files[k] : nullptr;
+        j.ppm_index = j.png_file ? (size_t)-1 : n_ppm++;
+        jobs.push_back(j);
+    }
+    auto device_of = [&](int k) { return available > 0 ? (prm.device + k) % available : prm.device + k; };
+    const bool frame_level = n_gpus > 1 && jobs.size() >= (size_t)n_gpus;
+    Shared shared;
+    shared.jobs = &jobs;
+    std::vector<Worker> workers(frame_level ? n_gpus : 1);
+    for (size_t k = 0; k < workers.size(); ++k) {
+        Worker &w = workers[k];
+        w.prm = prm;
+        w.shared = &shared;
+        if (frame_level)
+            w.prm.device = device_of((int)k);
+        else if (n_gpus > 1) {
+            w.group_size = n_gpus, w.group_rehearsal = rehearse;
+            for (int q = 0; q < n_gpus; ++q) w.group_devices.push_back(device_of(q));
+        }
+    }
+    if (workers.size() == 1)
+        workers[0].run();
+    else {
+        std::vector<std::thread> threads;
+        for (Worker &w : workers) threads.emplace_back([&w]() { w.run(); });
+        for (std::thread &t : threads) t.join();
+    }
+    return shared.exit_code.load();
 }

@@ -45,6 +45,10 @@ constexpr int kEventRing = 64;
 
 } // namespace
 
+namespace rrtx {
+int set_error(int code, const std::string &msg) { return fail(code, msg); } // for the other translation units of the library (rrtx_group.cpp)
+}
+
 struct rrtx_ctx {
     rrtx_params p;
     int device = 0;

@@ -183,6 +183,14 @@ struct FinalizeShape {
     int32_t chunks_per_pixel, chunk, spp;
 };
 
+// shape of a multi-device gather, for deinterleave_kernel (rrtx_group.cpp)
+constexpr int kMaxGroup = 64;
+struct GatherShape {
+    uint32_t row_values; // W * 3
+    uint32_t height, tile_rows, n_shards;
+    uint32_t row_off[kMaxGroup]; // rows of the shards before shard r in the gathered buffer
+};
+
 // Samples handed out as single-sample tasks at the end of the queue, per compute unit, when
 // rrtx_params.taper_samples is 0 (automatic).  Measured on final.txt 1200x800 with the queue-over flag,
 // pool parking and the unit split of parked items in place: none is best from spp 48 up (spp 504: 78.6 ms

@@ -1170,6 +1170,21 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
     }
 }
 
+// Multi-device gather, last step (rrtx_group.cpp): `gathered` holds the compact row blocks of the N shards
+// side by side (shard r from row GatherShape::row_off[r] on, its rows in ascending order); the frame's row j
+// belongs to shard (j / T) mod N, where it is local row (j / (T N)) T + j mod T.  One thread per value; pure
+// HBM traffic (read 12 B, write 12 B per pixel), 100 MB for a 4K frame.
+template <typename F> __global__ void __launch_bounds__(256) deinterleave_kernel(const F *__restrict__ gathered, F *__restrict__ frame, GatherShape S)
+{
+    const uint64_t n = (uint64_t)S.row_values * (uint64_t)S.height;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(v / S.row_values), x = (uint32_t)(v - (uint64_t)j * S.row_values);
+        const uint32_t tile = j / S.tile_rows, r = tile % S.n_shards;
+        const uint32_t lr = (tile / S.n_shards) * S.tile_rows + (j - tile * S.tile_rows);
+        frame[v] = gathered[((uint64_t)S.row_off[r] + lr) * S.row_values + x];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -1275,6 +1290,18 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     }
 }
 
+template <typename F> hipError_t launch_deinterleave(const F *gathered, F *frame, const GatherShape &S, hipStream_t stream)
+{
+    const uint64_t n = (uint64_t)S.row_values * S.height;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384; // (grid-stride: 64 blocks per CU)
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(deinterleave_kernel<F>, dim3((uint32_t)blocks), dim3(256), 0, stream, gathered, frame, S);
+    return hipGetLastError();
+}
+
+template hipError_t launch_deinterleave<float>(const float *, float *, const GatherShape &, hipStream_t);
+template hipError_t launch_deinterleave<double>(const double *, double *, const GatherShape &, hipStream_t);
 template hipError_t launch_render<float>(const KernelParams<float> &, bool, int, int, hipStream_t);
 template hipError_t launch_render<double>(const KernelParams<double> &, bool, int, int, hipStream_t);
 template hipError_t launch_primary_lists<float>(const KernelParams<float> &, uint16_t *, hipStream_t);

@@ -178,6 +178,74 @@ class Rrt:
         return self.stats
 
 
+class RrtGroup:
+    """One frame over several devices of one node, driven by this one process (include/rrtx.h, rrtx_group): row-tile
+    shards, one grouped RCCL send / recv to the first device, de-interleave there.  `devices` is a count (ordinals
+    0 .. n-1) or a list of ordinals; a list that repeats an ordinal needs rehearsal=True (the N-way decomposition
+    rehearsed on fewer GPUs: device-to-device copies instead of RCCL).  Same image as Rrt, bit for bit."""
+
+    def __init__(self, devices, image_width, image_height, samples_per_pixel, max_depth, use_bvh=True, *, fp64=False, seed=1984, sample_chunk=0, tile_rows=4,
+                 collect_stats=True, flags=0, rehearsal=False):
+        devs = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+        p = _lib.Params()
+        p.image_width, p.image_height = int(image_width), int(image_height)
+        p.samples_per_pixel, p.max_depth = int(samples_per_pixel), int(max_depth)
+        p.use_bvh = int(bool(use_bvh))
+        p.threads_x = p.threads_y = 8
+        p.fp64 = int(bool(fp64))
+        p.seed = int(seed)
+        p.sample_chunk = int(sample_chunk)
+        p.tile_rows = int(tile_rows)
+        p.collect_stats = int(bool(collect_stats))
+        p.flags = int(flags)
+        self.params, self.fp64, self.devices = p, bool(fp64), devs
+        self._g = C.c_void_p()
+        arr = (C.c_int32 * len(devs))(*devs)
+        check(lib.rrtx_group_create(C.byref(p), len(devs), arr, _lib.GROUP_REHEARSAL if rehearsal else 0, C.byref(self._g)), "rrtx_group_create")
+        self.stats = None
+        self._scene = None
+
+    def close(self):
+        g = getattr(self, "_g", None)
+        if g:
+            lib.rrtx_group_destroy(g)
+            self._g = None
+
+    __del__ = close
+
+    def __len__(self):
+        return lib.rrtx_group_size(self._g)
+
+    def member_rows(self, i):
+        ctx = C.c_void_p(lib.rrtx_group_member(self._g, i))
+        n = lib.rrtx_shard_rows(ctx, None, 0)
+        rows = (C.c_int32 * max(n, 1))()
+        lib.rrtx_shard_rows(ctx, rows, n)
+        return np.array(rows[:n], dtype=np.int32)
+
+    def set_scene(self, scene):
+        check(lib.rrtx_group_set_scene(self._g, C.byref(scene.desc)), "rrtx_group_set_scene")
+        self._scene = scene
+
+    def render(self, scene=None):
+        if scene is not None:
+            self.set_scene(scene)
+        p = self.params
+        fb = np.zeros((p.image_height, p.image_width, 3), dtype=np.float64 if self.fp64 else np.float32)
+        st = _lib.GroupStats()
+        check(lib.rrtx_group_render(self._g, fb.ctypes.data_as(C.c_void_p), C.byref(st)), "rrtx_group_render")
+        self.stats = st.as_dict()
+        return fb
+
+    def render_device(self):
+        """Render and leave the assembled frame on the first device; returns its device address."""
+        ptr = C.c_void_p()
+        st = _lib.GroupStats()
+        check(lib.rrtx_group_render_device(self._g, C.byref(ptr), C.byref(st)), "rrtx_group_render_device")
+        self.stats = st.as_dict()
+        return ptr.value
+
+
 def device_count():
     return lib.rrtx_device_count()
 
