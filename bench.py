@@ -5,42 +5,68 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over the workload: render the 1200x800 depth=50 fp32 frame of
-scenes/final.txt (scene tables already resident in HBM, framebuffer left in HBM) and, for N > 1, the
-one gather of the row-tile shards to rank 0 over RCCL.  N = 1 is BASELINE.json's configuration, spp = 500.
-N > 1 keeps the work per GPU fixed ("scaling": "weak", as the frame is a partitioned path): the same
-frame, row tiles dealt round-robin to the ranks, at spp = 500 x N — every rank traces 480 M samples, as
-BASELINE.json's own 8-GPU configuration scales the job (3840x2160 spp 1000) rather than splitting the
-1-GPU one.  `--strong` shards the spp = 500 frame instead (9.7 ms of work per GPU at N = 8; DESIGN.md has
-the fixed per-launch cost that then shows).  The image is bit-identical for every N and tile size.
+A step = one pass of the hot path over the workload: render the frame (scene tables already resident in HBM,
+framebuffer left in HBM) and, for N > 1, the one gather of the row-tile shards to rank 0 over RCCL.
 
-Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline     - logical primitive-read roofline of the render kernel: algorithmic bytes per launch
-                 (primitive tests x 16 B + framebuffer, counted on the device) / the kernel's mean
-                 launch duration (HIP events on the launch stream) against HBM3E's 8 TB/s.  The
-                 scene is 7.8 KB and lives in the scalar cache, so frac > 1 is expected; real HBM
-                 traffic (PMC) is reported beside it when profiles/ holds a measurement.
-  cpu_baseline - the reference's own OpenMP binary (oracle/_ref/rrto, built from the reference
-                 sources) timed here on the host cores, on a bounded sample of the same scene.
+Workloads (BASELINE.json `configs`):
+  N = 1   C3 = scenes/final.txt 1200x800 spp 500 d 50 fp32, brute-force list scan (the mode north_star names and
+          the roofline is defined for) - the configuration the metric is quoted on.  The same line carries, timed by
+          this run: `accelerated` (C3 with use_bvh, the CLI's default mode) and `configs` = C2 (test1 1200x800
+          spp 10), C4 (final fp64), C5 on ONE GPU (final 3840x2160 spp 1000), each in both modes.
+  N > 1   C5 = scenes/final.txt 3840x2160 spp 1000 fp32 cut into row tiles over the N ranks ("scaling": "strong":
+          the total is BASELINE.json's 8-GPU job whatever N is), one RCCL gather to rank 0 per step; the line reports
+          the kernel-only time (slowest rank) next to the gather-inclusive step time.  `--strong-c3` shards C3
+          instead (9.7 ms of work per GPU at N = 8), `--weak` keeps 480 M samples per GPU (C3 at spp 500 x N).
+The image is bit-identical for every N and tile size (tests/test_gpu_configs.py, tests/test_gpu_group.py).
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields:
+  roofline     - for the dominant kernel, against the unit that BINDS it.  There is no dense contraction on this path
+                 (no MFMA) and the scene is 7.8 KB (no HBM stream): the kernel is bound by VALU issue.  `achieved` =
+                 VALU wave-instructions per clock per SIMD, `peak` = 0.5 (one wave-instruction every second clock:
+                 157.3 TFLOP/s fp32 = 256 CUs x 4 SIMDs x 32 FMA lanes x 2.4 GHz), `frac` = achieved / peak <= 1.
+                 At N = 1 the counters come from rocprofv3 --pmc passes THIS run makes (SQ_INSTS_VALU & co. in one
+                 pass, FETCH_SIZE and WRITE_SIZE in passes of their own - the HBM `traffic`), on the `rrt` binary
+                 rendering the same workload through the same library, before this process touches the GPU.
+                 `logical_hbm` keeps SURVEY.md 8(d)'s figure - algorithmic bytes of the reference's list scan / kernel
+                 time against 8 TB/s - as a named field: it exceeds 1 by construction (one 16-byte record read serves
+                 64 rays, camera rays are resolved from per-pixel lists) and says nothing about kernel quality.
+  cpu_baseline - the reference's own OpenMP binary (oracle/_ref/rrto, built from the reference sources) timed here
+                 on the host cores, on a bounded sample of the same scene.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SCENE = os.path.join(ROOT, "scenes", "final.txt")
-WIDTH, HEIGHT, SPP, DEPTH = 1200, 800, 500, 50
+TEST1 = os.path.join(ROOT, "scenes", "test1.txt")
+DEPTH = 50
+C3 = (1200, 800, 500)
+C5 = (3840, 2160, 1000)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK = 0.5        # VALU wave-instructions per clock per SIMD: a wave64 instruction occupies the 32-lane fp32 pipe for 2 clocks
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9       # nominal; a PMC pass measures the real one (GRBM_GUI_ACTIVE / 8 XCDs / duration)
+LIST_KERNEL = "render_kernel<float, true, 1, false, 0, false>"
+ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false>"
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the reference's own binaries; test infrastructure, never the thing measured as `value`)
+# ------------------------------------------------------------------------------------------------------------------
 def cpu_baseline():
-    """Reference CPU build on a bounded sample (~10-30 s of CPU work).  Test infrastructure only."""
+    """Reference CPU build on a bounded sample (~10-30 s of CPU work)."""
     ref = os.path.join(ROOT, "oracle", "_ref")
     rrto, rrtc = os.path.join(ref, "rrto"), os.path.join(ref, "rrtc")
 
@@ -68,7 +94,7 @@ def cpu_baseline():
         w2, h2, s2 = 600, 400, 4
         sec_b, _ = run(rrto, ["-w", str(w2), "-h", str(h2), "-s", str(s2), "-b"], env=omp_env)
         out["brute_force_value"] = round(w2 * h2 * s2 / sec_b / 1e6, 4)
-        out["brute_force_sample"] = "rrto -b (list scan, the mode the HIP kernel implements) %dx%d spp=%d: %.2f s" % (w2, h2, s2, sec_b)
+        out["brute_force_sample"] = "rrto -b (list scan, the mode the headline HIP kernel implements) %dx%d spp=%d: %.2f s" % (w2, h2, s2, sec_b)
         sec_c, _ = run(rrtc, ["-w", str(w2), "-h", str(h2), "-s", str(s2)])
         out["single_thread_value"] = round(w2 * h2 * s2 / sec_c / 1e6, 4)
         out["single_thread_sample"] = "oracle/_ref/rrtc (1 thread fp32, BVH) %dx%d spp=%d: %.2f s" % (w2, h2, s2, sec_c)
@@ -86,50 +112,150 @@ def cpu_baseline():
             "sample": "oracle/librrt_oracle.so (OpenMP port, brute-force list scan, fp32) on scenes/final.txt %dx%d spp=%d: %.2f s" % (w, h, s, sec)}
 
 
-def measured_traffic():
-    """HBM bytes per launch from a committed rocprofv3 PMC run of this same command (or None)."""
-    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+# ------------------------------------------------------------------------------------------------------------------
+# live PMC passes: rocprofv3 on the `rrt` binary (a separate process), BEFORE this process initialises the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def kernel_source_hash():
+    """What the committed fallback profile is checked against: the device code it was measured on."""
+    h = hashlib.sha256()
+    for f in ("rrtx_kernels.hip", "rrtx_path.h", "rrtx_device.h", "rrtx_grid.h"):
+        h.update(open(os.path.join(ROOT, "rrt_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def measured_valu_issue():
-    """VALU issue utilisation of the headline kernel from the committed PMC summary (or None)."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_render_kernel.csv")
+def pmc_pass(counters, rrt_args, want_kernel, timeout=100):
+    """One `rocprofv3 --pmc <counters>` run (no tracing) of ./rrt <rrt_args>; -> {counter: per-launch value of
+    `want_kernel`, "duration_ms": ...} or None.  The program itself follows `--` (no env / shell hop)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="rrtx_pmc_", dir="/tmp")
     try:
-        for line in open(p):
-            if line.startswith("valu_issue_utilisation,"):
-                return float(line.split(",")[1])  # the first block of the file is the list-scan kernel
+        png = os.path.join(out, "frame.png")
+        cmd = [exe, "--output-format", "csv", "--pmc"] + list(counters) + ["-d", out, "-o", "p", "--", os.path.join(ROOT, "rrt")] + list(rrt_args) + ["-o", png]
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        if r.returncode != 0:
+            return None
+        acc, n, dur = {}, {}, []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if want_kernel in row["Kernel_Name"]:
+                    c = row["Counter_Name"]
+                    acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+                    n[c] = n.get(c, 0) + 1
+                    try:
+                        dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+                    except Exception:
+                        pass
+        if not acc:
+            return None
+        res = {c: acc[c] / n[c] for c in acc}  # one row per (dispatch, counter): the mean over this kernel's dispatches = per launch
+        res["launches"] = max(n.values())
+        if dur:
+            res["duration_ms"] = sum(dur) / len(dur)
+        return res
     except Exception:
-        pass
-    return None
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
+def live_pmc(w, h, spp):
+    """The passes behind roofline.frac and roofline.traffic (list scan) and the accelerated kernel's lane utilisation."""
+    base = ["-i", SCENE, "-w", str(w), "-h", str(h), "-s", str(spp), "-d", str(DEPTH)]
+    sq = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    res = {"source": "rocprofv3 --pmc passes made by this bench.py run on `rrt` (same library, same workload), one counter group per pass, no tracing",
+           "kernel_source_sha": kernel_source_hash()}
+    a = pmc_pass(sq, base + ["-b"], LIST_KERNEL)
+    if not a:
+        return None
+    res["list_scan"] = a
+    f = pmc_pass(["FETCH_SIZE"], base + ["-b"], LIST_KERNEL)
+    wv = pmc_pass(["WRITE_SIZE"], base + ["-b"], LIST_KERNEL)
+    if f and wv:
+        # MI355X_MICROARCH.md "HBM": FETCH_SIZE (KB) reports half of the bytes read on gfx950; WRITE_SIZE (KB) is exact
+        res["hbm_read_bytes"] = int(f["FETCH_SIZE"] * 1024 * 2)
+        res["hbm_write_bytes"] = int(wv["WRITE_SIZE"] * 1024)
+    g = pmc_pass(sq, base, ACCEL_KERNEL)
+    if g:
+        res["accelerated"] = g
+    return res
+
+
+def committed_pmc():
+    """Fallback when no pass can be made here: the committed profile, only if it was measured on THIS device code."""
+    p = os.path.join(ROOT, "profiles", "r02_pmc_live.json")
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None
+    if d.get("kernel_source_sha") != kernel_source_hash():
+        return None  # stale: the kernels changed since it was taken
+    d["source"] = "profiles/r02_pmc_live.json (committed; measured on the same device code: sha %s)" % d["kernel_source_sha"]
+    return d
+
+
+def valu_numbers(pm):
+    """-> (wave-instructions / clk / SIMD, lane utilisation, clock GHz or None) from one SQ pass."""
+    cycles = pm["GRBM_GUI_ACTIVE"] / 8.0  # per XCD
+    per_clk = pm["SQ_INSTS_VALU"] / (N_SIMD * cycles)
+    lanes = pm["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]) if pm.get("SQ_ACTIVE_INST_VALU") else None
+    ghz = cycles / (pm["duration_ms"] * 1e-3) / 1e9 if pm.get("duration_ms") else None
+    return per_clk, lanes, ghz
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (non-headline runs only); default 500 x N (weak scaling)")
-    ap.add_argument("--strong", action="store_true", help="N > 1: shard the spp = 500 frame (fixed total work) instead of scaling spp with N")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (non-headline runs only)")
+    ap.add_argument("--strong-c3", action="store_true", help="N > 1: shard configuration 3 (1200x800 spp 500) instead of configuration 5")
+    ap.add_argument("--weak", action="store_true", help="N > 1: keep the work per GPU fixed (configuration 3 at spp 500 x N)")
     ap.add_argument("--tile-rows", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="skip the extra use_bvh measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C4 / C5-on-one-GPU sub-results")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (a committed profile is used if it matches the device code)")
     args = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises the HIP runtime (RCCL IPC on this pool)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+
+    # workload
+    if world == 1 or args.strong_c3 or args.weak:
+        W, H, spp = C3
+        if args.weak:
+            spp *= world
+        wl_name = "C3"
+    else:
+        W, H, spp = C5
+        wl_name = "C5"
+    if args.spp > 0:
+        spp = args.spp
+    headline = world == 1 and (W, H, spp) == C3
+
+    # ---- PMC first: this process has not touched the GPU yet, rocprofv3 profiles a child (`rrt`)
+    pmc = None
+    # (never from inside a profiler: `rocprofv3 -- python3 bench.py` must not start a second one underneath itself)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and headline and not args.no_pmc and not under_profiler:
+        try:
+            pmc = live_pmc(W, H, spp)
+        except Exception:
+            pmc = None
+    if world == 1 and headline and pmc is None:
+        pmc = committed_pmc()
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible - the render path has no CPU fallback")
     # one rank per GPU.  RRTX_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
@@ -139,69 +265,102 @@ def main():
     device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+    dev = torch.device("cuda", device_index)
 
+    import rrt_amd
     from rrt_amd.dist import ShardedRenderer
-
-    if args.spp <= 0:
-        args.spp = SPP if args.strong else SPP * world
-
-    sr = ShardedRenderer(SCENE, WIDTH, HEIGHT, args.spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=torch.device("cuda", device_index), collect_stats=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sr.render()
-    barrier()
-    sr.rrt.collect()  # drop warm-up launches from the event statistics
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sr.render()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st = sr.rrt.collect()
+    def reduce_max(x):
+        if world > 1:
+            tt = torch.tensor([x], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    def timed(sr, steps, warmup, gather=True):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.  -> (seconds, stats)"""
+        step = sr.render if gather else sr.render_local
+        for _ in range(warmup):
+            step()
+        barrier()
+        sr.rrt.collect()  # drop warm-up launches from the event statistics
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        return reduce_max(time.perf_counter() - t0), sr.rrt.collect()
+
+    sr = ShardedRenderer(SCENE, W, H, spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=dev, collect_stats=True)
+    elapsed, st = timed(sr, args.steps, args.warmup)
+    kernel_only = None
+    if world > 1:  # the same steps without the gather: what the exchange adds
+        ko, _ = timed(sr, args.steps, 0, gather=False)
+        kernel_only = ko / args.steps * 1e3
 
     # the same steps with use_bvh (the CLI's default; SURVEY.md 8(f) N1): reported beside the headline, which
     # stays the list scan the north star names and the roofline is defined for
     accel = None
     if not args.no_accel:
-        sa = ShardedRenderer(SCENE, WIDTH, HEIGHT, args.spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=torch.device("cuda", device_index), collect_stats=True, use_bvh=True)
-        sa.render()
-        barrier()
-        sa.rrt.collect()
-        barrier()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            sa.render()
-        barrier()
-        elapsed_a = time.perf_counter() - ta
-        if world > 1:
-            tt = torch.tensor([elapsed_a], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed_a = float(tt.item())
-        sta = sa.rrt.collect()
-        accel = {"value": round(WIDTH * HEIGHT * args.spp / (elapsed_a / args.steps) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(elapsed_a / args.steps * 1e3, 3),
+        sa = ShardedRenderer(SCENE, W, H, spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=dev, collect_stats=True, use_bvh=True)
+        elapsed_a, sta = timed(sa, args.steps, 1)
+        accel = {"value": round(W * H * spp / (elapsed_a / args.steps) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(elapsed_a / args.steps * 1e3, 3),
                  "kernel_ms": round(sta["kernel_ms_sum"] / max(1, sta["renders"]), 3), "grid_cells": sta["accel_cells"],
-                 "note": "use_bvh = 1: closest hit through a uniform grid + always-list, exact test and tie rules of the list scan, image bit-identical (tests/test_gpu_parity.py); "
-                         "its segments fall back to the list scan only for rays outside the grid's proven range (DESIGN.md)"}
+                 "note": "use_bvh = 1 (the CLI's default, as the reference's BVH is): closest hit through a uniform grid + always-list, exact test and tie rules of the list scan, "
+                         "image bit-identical (tests/test_gpu_configs.py); segments fall back to the list scan only for rays outside the grid's proven range (DESIGN.md 3b)"}
+        if pmc and pmc.get("accelerated"):
+            pc, lanes, _ = valu_numbers(pmc["accelerated"])
+            accel["valu_issue_frac"] = round(pc / VALU_PEAK, 4)
+            accel["valu_lane_utilisation"] = round(lanes, 4) if lanes else None
         del sa
 
-    # per-rank kernel statistics -> whole-job roofline numbers
+    # ---- the other configurations of BASELINE.json, timed by this run (N = 1 only)
+    configs = None
+    if world == 1 and headline and not args.no_configs:
+        configs = {}
+
+        def one(name, scene, w, h, s, fp64, steps):
+            ent = {"workload": "%s %dx%d spp=%d d=%d %s on 1 GPU" % (os.path.relpath(scene, ROOT), w, h, s, DEPTH, "fp64" if fp64 else "fp32")}
+            for mode, bvh in (("list_scan", False), ("use_bvh", True)):
+                r = ShardedRenderer(scene, w, h, s, DEPTH, fp64=fp64, tile_rows=args.tile_rows, device=dev, collect_stats=True, use_bvh=bvh)
+                sec, stt = timed(r, steps, 1)
+                ent[mode] = {"ms_per_step": round(sec / steps * 1e3, 3), "kernel_ms": round(stt["kernel_ms_sum"] / max(1, stt["renders"]), 3), "Msamples_per_s": round(w * h * s / (sec / steps) / 1e6, 1),
+                             "sample_chunk": stt["sample_chunk"], "grid_cells": stt["accel_cells"]}
+                del r
+            configs[name] = ent
+
+        one("C2", TEST1, 1200, 800, 10, False, 20)
+        one("C4", SCENE, 1200, 800, 500, True, 3)
+        one("C5_on_1_gpu", SCENE, C5[0], C5[1], C5[2], False, 2)
+        # ... and the native single-process group (rrtx_group: RCCL send / recv + de-interleave) with the devices of this box
+        try:
+            g = rrt_amd.RrtGroup(torch.cuda.device_count(), W, H, spp, DEPTH, use_bvh=False, tile_rows=args.tile_rows)
+            g.set_scene(rrt_amd.Scene(SCENE, W, H))
+            g.render_device()
+            ds = []
+            for _ in range(3):
+                g.render_device()
+                ds.append(dict(g.stats))
+            best = min(ds, key=lambda d: d["device_ms"])
+            configs["C3_native_group"] = {"n_devices": best["n_devices"], "rccl": best["rccl"], "render_ms": round(best["render_ms"], 3), "device_ms": round(best["device_ms"], 3),
+                                          "gather_ms": round(best["gather_ms"], 3), "gathered_bytes": best["gathered_bytes"],
+                                          "note": "rrtx_group_render_device: one process, ncclCommInitAll + grouped ncclSend / ncclRecv to device 0 + de-interleave; device_ms = first launch -> assembled frame"}
+            g.close()
+        except Exception as e:
+            configs["C3_native_group"] = {"error": repr(e)}
+
+    # per-rank kernel statistics -> whole-job numbers
     vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"]), float(st["scanned_segments"]),
-                        float(st["candidates"])], dtype=torch.float64,
-                       device="cuda" if backend == "nccl" else "cpu")
+                        float(st["candidates"])], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         allv = [torch.zeros_like(vec) for _ in range(world)]
         dist.all_gather(allv, vec)
@@ -214,9 +373,36 @@ def main():
         prim_tests = sum(float(v[3]) for v in allv)
         scanned = sum(float(v[4]) for v in allv)
         candidates = sum(float(v[5]) for v in allv)
-        samples = WIDTH * HEIGHT * args.spp
+        samples = W * H * spp
         ms_per_step = elapsed / args.steps * 1e3
-        achieved = total_bytes / (kernel_ms * 1e-3) / 1e9 / world  # GB/s per GPU
+        logical = total_bytes / (kernel_ms * 1e-3) / 1e9 / world  # GB/s per GPU
+
+        # ---- the binding unit: VALU issue
+        clock = CLOCK_HZ
+        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD", "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL, "kernel_ms": round(kernel_ms, 3)}
+        if pmc and pmc.get("list_scan"):
+            per_clk, lanes, ghz = valu_numbers(pmc["list_scan"])
+            if ghz:
+                clock = ghz * 1e9
+            roof.update({"achieved": round(per_clk, 4), "frac": round(per_clk / VALU_PEAK, 4), "valu_lane_utilisation": round(lanes, 4) if lanes else None,
+                         "shader_clock_GHz": round(ghz, 3) if ghz else None, "counters": {k: v for k, v in pmc["list_scan"].items()}, "source": pmc["source"], "kernel_source_sha": pmc.get("kernel_source_sha")})
+            roof["traffic"] = (pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) if "hbm_read_bytes" in pmc else None
+            if "hbm_read_bytes" in pmc:
+                roof["traffic_detail"] = {"read_bytes": pmc["hbm_read_bytes"], "write_bytes": pmc["hbm_write_bytes"], "hbm_GBs": round((pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) / (kernel_ms * 1e-3) / 1e9, 1),
+                                          "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, separate passes; per launch"}
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None, "source": "no PMC pass possible in this run and no committed profile of this device code"})
+        # the part of it the run can count itself: the scan filter's 8 VALU instructions per executed (ray, sphere) test
+        tests_executed = scanned / world * 488  # per GPU (wave-level: one test = 8 wave-instructions for 64 rays)
+        filt = tests_executed * 8 / 64 / (kernel_ms * 1e-3 * N_SIMD * clock)
+        roof["filter_only"] = {"achieved": round(filt, 4), "frac": round(filt / VALU_PEAK, 4),
+                               "note": "lower bound counted by the kernel itself: 8 VALU instructions per executed (ray, sphere) filter test x scanned segments x 488 / 64 lanes, over kernel time x 1024 SIMDs x clock"}
+        if roof.get("frac") is None:
+            roof["achieved"], roof["frac"] = roof["filter_only"]["achieved"], roof["filter_only"]["frac"]
+            roof["source"] += "; achieved / frac = the filter-only lower bound"
+        roof["logical_hbm"] = {"achieved": round(logical, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(logical / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(total_bytes / world),
+                               "note": "SURVEY.md 8(d): what the REFERENCE's list scan reads (segments x 488 spheres x 16 B + frame) / kernel time against HBM3E's 8 TB/s. Not a physical fraction: "
+                                       "the 7.8 KB scene is read from the scalar cache / LDS, one record read serves the 64 rays of a wave, camera rays are resolved from per-pixel lists"}
         line = {
             "metric": "Msamples/s (WxHxspp) on scenes/final.txt fp32",
             "value": round(samples / (ms_per_step * 1e-3) / 1e6, 2),
@@ -226,21 +412,23 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "scenes/final.txt %dx%d spp=%d d=%d fp32, brute-force list scan (488 spheres)" % (WIDTH, HEIGHT, args.spp, DEPTH), "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", RCCL gather to rank 0" if world > 1 else ""),
+            "config": {"workload": "%s: scenes/final.txt %dx%d spp=%d d=%d fp32, brute-force list scan (488 spheres)" % (wl_name, W, H, spp, DEPTH),
+                       "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", one RCCL gather to rank 0 per step" if world > 1 else ""),
                        "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests),
                        "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic() if world == 1 and args.spp == SPP else None,
-                         "kernel": "rrtx::render_kernel<float, true, 1, false, 0, false>", "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(total_bytes / world),
-                         "valu_issue": {"filter_frac": round(float(scanned / world * 488) * 8 / 64 / (kernel_ms * 1e-3 * 1024 * 2.4e9 * 0.5), 4), "pmc_frac": measured_valu_issue() if world == 1 and args.spp == SPP else None,
-                                        "note": "the unit that binds: wave-instructions per clock per SIMD against the peak of 0.5 (256 CUs x 4 SIMDs at 2.4 GHz); filter_frac counts only the scan filter's 8 instructions per executed (ray, sphere) test of this run, pmc_frac is SQ_INSTS_VALU of the committed rocprofv3 pass (profiles/r01_pmc_render_kernel.csv)"},
-                         "note": "logical primitive-read roofline (SURVEY.md 8d): algorithmic bytes = what the reference's list scan reads (segments x 488 spheres x 16 B); a record read from the scalar cache or LDS serves all 64 rays of a wave and camera rays are resolved from per-pixel candidate lists (config.prim_tests_executed_per_launch), so frac > 1 is legitimate; binding unit: VALU issue (DESIGN.md 3)"},
+            "roofline": roof,
         }
+        if kernel_only is not None:
+            line["kernel_only_ms_per_step"] = round(kernel_only, 3)
+            line["gather_ms_per_step"] = round(max(0.0, ms_per_step - kernel_only), 3)
         if accel is not None:
             line["accelerated"] = accel
+        if configs is not None:
+            line["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

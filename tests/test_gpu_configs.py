@@ -113,7 +113,7 @@ def test_config5_final_3840x2160_spp1000_as_8_shards(gpu):
     assert chunk == 128, chunk  # the per-task partial sums of the FULL frame stay under 2 GiB (rrtx_create)
     cpp = (spp + chunk - 1) // chunk
     assert w * h * cpp < 2 ** 31 and st["samples"] == w * h * spp
-    assert 2.51 < st["segments"] / st["samples"] < 2.54
+    assert 2.47 < st["segments"] / st["samples"] < 2.52  # (16:9 here against 3:2 in C3: more sky in the frame, 2.4935)
     assert np.isfinite(full).all() and (full >= 0).all()
     o = Oracle(FINAL, w, h, False)
     j = 1049  # through the three large spheres
