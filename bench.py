@@ -221,6 +221,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (a committed profile is used if it matches the device code)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: RCCL greets on stdout ("RCCL version : ...") when a communicator is
+    # built, child processes may chatter - so file descriptor 1 points at stderr for the duration of the run and the
+    # line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises the HIP runtime (RCCL IPC on this pool)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -434,7 +440,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # never lose the GPU measurement to a CPU-side hiccup
                 line["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

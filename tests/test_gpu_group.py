@@ -50,6 +50,17 @@ def test_one_device_through_the_rccl_path(gpu, fp64):
     assert np.array_equal(want[5], Oracle(FINAL, w, h, fp64).render(spp, 50, 1984, order=1, chunk=8, rows=(5, 6))[0][5])
 
 
+def test_rccl_does_not_talk_on_stdout(gpu):
+    # stdout belongs to the PPM (main.cpp:142); RCCL prints a version banner there when a communicator is built
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import rrt_amd; g = rrt_amd.RrtGroup(1, 32, 20, 2, 5); "
+            "g.render(rrt_amd.Scene(%r, 32, 20)); assert g.stats['rccl'] == 1; g.close()" % (ROOT, TEST3))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == b"", r.stdout
+
+
 def test_every_device_of_the_box(gpu):
     n = gpu.device_count()
     w, h, spp = 160, 100, 6

@@ -1,19 +1,32 @@
 #!/bin/bash
-# Developer helper (GPU box): the measurements behind profiles/r01_* — bench line, kernel trace, PMC passes.
+# Developer helper (GPU box): the measurements behind profiles/<tag>_* — bench line (with its live PMC passes), kernel
+# trace of the same command, and one rocprofv3 --pmc pass per counter group (never combined with tracing) for the four
+# headline kernels: list scan / accelerated x fp32 / fp64, each on the `rrt` / `rrtd` binary rendering configuration 3.
+#   gpurun -- 'bash tools/profile_round.sh r02'
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err || tail -3 $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/trace.err || tail -3 $O/trace.err
-i=0
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SMEM SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1))
-  timeout -k 10 200 rocprofv3 --output-format csv --pmc $grp -d $O/p$i -o p$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc$i.json 2> $O/pmc$i.err || tail -3 $O/pmc$i.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pmc > $O/bench_under_rocprof.json 2> $O/trace.err || tail -3 $O/trace.err
+ARGS="-i $R/scenes/final.txt -w 1200 -h 800 -s 500 -d 50"
+for variant in list_f32 accel_f32 list_f64 accel_f64; do
+  case $variant in
+    list_f32)  EXE=$R/rrt;  EXTRA="-b" ;;
+    accel_f32) EXE=$R/rrt;  EXTRA="" ;;
+    list_f64)  EXE=$R/rrtd; EXTRA="-b" ;;
+    accel_f64) EXE=$R/rrtd; EXTRA="" ;;
+  esac
+  i=0
+  for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SMEM SQ_LDS_IDX_ACTIVE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout -k 10 120 rocprofv3 --output-format csv --pmc $grp -d $O/$variant/p$i -o p$i -- $EXE $ARGS $EXTRA -o $O/$variant.png > /dev/null 2> $O/$variant.p$i.err || tail -3 $O/$variant.p$i.err
+  done
 done
 cd $R
-for k in "render_kernel<float, true, 1, false, 0, false>" "render_kernel<float, true, 0, false, 2, false>" "render_kernel<float, true, 0, false, 2, true>" tail_kernel; do echo "== $k"; PMC_KERNEL="$k" python3 tools/pmc_summary.py $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 $O/p8; done > $O/pmc_summary.txt
-cat $O/trace/*kernel_stats.csv | head -12
-cat $O/pmc_summary.txt
+python3 tools/pmc_report.py $O > $O/pmc_report.csv
+cat $O/trace/*kernel_stats.csv | head -14
+cat $O/pmc_report.csv
