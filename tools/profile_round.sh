@@ -11,7 +11,7 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err || tail -3 $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pmc > $O/bench_under_rocprof.json 2> $O/trace.err || tail -3 $O/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pmc --no-configs > $O/bench_under_rocprof.json 2> $O/trace.err || tail -3 $O/trace.err
 ARGS="-i $R/scenes/final.txt -w 1200 -h 800 -s 500 -d 50"
 for variant in list_f32 accel_f32 list_f64 accel_f64; do
   case $variant in
