@@ -104,9 +104,9 @@ typedef struct rrtx_params {
     int32_t max_depth;                 /* -d                                               */
     int32_t use_bvh;                   /* -b clears it (main.cpp:67,90).  Non-zero: segments are resolved
                                           through an acceleration grid when the scene allows one
-                                          (rrtx_stats.accel_cells; spheres always, triangle meshes
-                                          in fp64 only); zero: the hittable_list scan.
-                                          Same image either way, bit for bit.                    */
+                                          (rrtx_stats.accel_cells); zero: the hittable_list scan.
+                                          Same image either way, bit for bit - except fp32 triangle
+                                          meshes, see RRTX_FLAG_EXACT_ACCEL / rrtx_stats.accel_exact.  */
     int32_t threads_x, threads_y;      /* -tx / -ty: accepted; reported in the stats line    */
     int32_t fp64;                      /* 0 = `rrt` (float), 1 = `rrtd` (double)            */
     int32_t device;                    /* HIP device ordinal (-D)                           */
@@ -152,6 +152,15 @@ typedef struct rrtx_params {
  * lane; rrtx_stats.list_mismatches counts the rays for which the two disagree (must stay 0).
  * With use_bvh the same is done for every segment resolved through the acceleration grid. */
 #define RRTX_FLAG_VERIFY_LISTS 32
+/* use_bvh in fp32 with triangle meshes: keep the list scan's bits at any price.  Without this flag a mesh is entered
+ * into the acceleration grid under an empirical inflation (rrtx_grid.h, kApproxTriInflation): the reference's
+ * triangle test (triangle.h:38-75), evaluated in fp32, reports hits on rays that graze a triangle's plane from far
+ * outside it, no finite inflation is PROVEN to catch them all, and a ray segment in ~10^-5 (measured, bounded by
+ * tests/test_gpu_mesh.py) then resolves differently from the sequential scan - exactly where the reference's own BVH
+ * (its default; bvh.h:167-175) differs from its own `-b` list scan.  rrtx_stats.accel_exact says which rule is in use;
+ * spheres, moving spheres and fp64 meshes are always under the proven rule.  With this flag fp32 triangles stay
+ * outside the grid (always-list of <= 48, else the whole scene is scanned: O(n) per segment). */
+#define RRTX_FLAG_EXACT_ACCEL 64
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
@@ -173,6 +182,9 @@ typedef struct rrtx_stats {
     int32_t list_mismatches; /* RRTX_FLAG_VERIFY_LISTS: camera rays whose list hit != scan hit */
     uint64_t scanned_segments; /* segments that went through the full primitive scan (the others
                                   are camera rays resolved from their pixel's candidate list)  */
+    int32_t accel_exact;     /* 1: the closest hit in use is proven to equal the list scan's bit for bit (always, unless
+                                fp32 triangles were entered into the grid under the approximate rule: 0)              */
+    int32_t reserved;
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

@@ -74,6 +74,8 @@ class Stats(C.Structure):  # rrtx_stats
         ("scan_filter", C.c_int32),
         ("list_mismatches", C.c_int32),
         ("scanned_segments", C.c_uint64),
+        ("accel_exact", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
@@ -181,6 +183,7 @@ _sig("rrtx_write_png", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int])
 
 
 FLAG_EXACT_SCAN = 1
+FLAG_EXACT_ACCEL = 64
 
 
 class RrtxError(RuntimeError):

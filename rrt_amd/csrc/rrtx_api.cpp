@@ -78,7 +78,8 @@ struct rrtx_ctx {
     // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
     bool accel = false;
     uint32_t *d_grid_cell_start = nullptr, *d_grid_always = nullptr;
-    uint16_t *d_grid_cell_prims = nullptr;
+    GridPrim *d_grid_cell_prims = nullptr;
+    bool accel_exact = true; // the grid is proven to reproduce the list scan bit for bit (false: fp32 triangles gridded under the approximate rule)
     int n_grid_cells = 0, n_grid_prims = 0, n_always = 0;
     unsigned char grid_bytes[sizeof(GridRec<double>)];
     void *d_tail_items = nullptr; // parked work items (render kernel -> tail kernel)
@@ -162,16 +163,22 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     c->accel = false;
     if (c->p.use_bvh && c->tail_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN)) {
         std::vector<uint32_t> cell_start, always;
-        std::vector<uint16_t> cell_prims;
+        std::vector<GridPrim> cell_prims;
         GridRec<F> G = {};
         CameraRec<F> camrec;
         memcpy(&camrec, c->cam_bytes, sizeof camrec);
-        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G)) {
+        // Triangles whose test the grid is not PROVEN to cover (fp32: practically all, rrtx_grid.h) are gridded all the same,
+        // under an empirical inflation, unless the caller insists on the list scan's bits (RRTX_FLAG_EXACT_ACCEL): the
+        // reference's own default, its BVH, has the same hazard band against its own list scan (bvh.h:167-175)
+        bool approximate = false;
+        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G, !(c->p.flags & RRTX_FLAG_EXACT_ACCEL),
+                          &approximate)) {
+            c->accel_exact = !approximate;
             if (cell_prims.empty()) cell_prims.push_back(0);
             if (always.empty()) always.push_back(0), c->n_always = 0;
             else c->n_always = (int)always.size();
             if ((rc = up((void **)&c->d_grid_cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
-            if ((rc = up((void **)&c->d_grid_cell_prims, cell_prims.data(), cell_prims.size() * 2))) return rc;
+            if ((rc = up((void **)&c->d_grid_cell_prims, cell_prims.data(), cell_prims.size() * sizeof(GridPrim)))) return rc;
             if ((rc = up((void **)&c->d_grid_always, always.data(), always.size() * 4))) return rc;
             c->n_grid_cells = (int)cell_start.size() - 1;
             c->n_grid_prims = (int)cell_start.back();
@@ -599,6 +606,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->block_threads = kBlockThreads;
         stats->sample_chunk = c->chunk;
         stats->accel_cells = c->accel ? c->n_grid_cells : 0;
+        stats->accel_exact = c->accel ? (c->accel_exact ? 1 : 0) : 1;
         stats->local_rows = c->local_rows;
         stats->scan_filter = c->use_filter ? 1 : 0;
     }

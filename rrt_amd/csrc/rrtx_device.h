@@ -104,6 +104,7 @@ template <typename F> struct TailItem {
 // boxes of all primitives that are not much larger than a cell; the few that are (the ground sphere)
 // sit in an "always" list tested for every segment.  Cell c lists primitives cell_start[c] ..
 // cell_start[c + 1] of cell_prims (unified primitive indices).
+typedef uint32_t GridPrim; // an entry of cell_prims (16 bits were enough for final.txt; a mesh of 100 000 triangles is not)
 template <typename F> struct GridRec {
     F gmin[3], gmax[3];  // box of the grid
     F cell[3], inv_cell[3];
@@ -168,7 +169,7 @@ template <typename F> struct KernelParams {
     unsigned long long *diag; // RRTX_DIAG builds only (timing stamps), otherwise unused
     // accelerated closest hit (all null / 0 when the list scan is used)
     const uint32_t *grid_cell_start; // [cells + 1]
-    const uint16_t *grid_cell_prims;
+    const GridPrim *grid_cell_prims;
     const uint32_t *grid_always;
     int32_t n_always, n_grid_cells, n_grid_prims;
     GridRec<F> grid;

@@ -223,7 +223,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     // ACCEL == 2: [exact-test records][cell_start][cell_prims] in LDS
     SphereHot<F> *const hot_lds = (SphereHot<F> *)dyn_lds;
     uint32_t *const cell_start_lds = (uint32_t *)(hot_lds + P.n_sph_padded);
-    uint16_t *const cell_prims_lds = (uint16_t *)(cell_start_lds + P.n_grid_cells + 1);
+    GridPrim *const cell_prims_lds = (GridPrim *)(cell_start_lds + P.n_grid_cells + 1);
     if (ACCEL == 2) {
         for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) hot_lds[i] = P.sph_hot[i];
         for (int i = threadIdx.x; i <= P.n_grid_cells; i += kBlockThreads) cell_start_lds[i] = P.grid_cell_start[i];
@@ -1196,7 +1196,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> hipError
 // bytes of LDS the accelerated variant wants for its tables (0: they stay in HBM)
 template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
 {
-    const size_t b = (size_t)P.n_sph_padded * sizeof(SphereHot<F>) + ((size_t)P.n_grid_cells + 1) * 4 + (((size_t)P.n_grid_prims * 2 + 15) & ~(size_t)15);
+    const size_t b = (size_t)P.n_sph_padded * sizeof(SphereHot<F>) + ((size_t)P.n_grid_cells + 1) * 4 + (((size_t)P.n_grid_prims * sizeof(GridPrim) + 15) & ~(size_t)15);
     return b <= (size_t)kLdsSceneBytes ? b : 0;
 }
 template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)

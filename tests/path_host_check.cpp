@@ -26,7 +26,7 @@ template <typename F> struct Scene {
     CameraRec<F> cam = {};
     KernelParams<F> P = {};
     std::vector<uint32_t> cell_start, always;
-    std::vector<uint16_t> cell_prims;
+    std::vector<GridPrim> cell_prims;
 };
 
 template <typename F> static void add_sphere(Scene<F> &s, double x, double y, double z, double r)

@@ -37,7 +37,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
     P.taper_pixel = (uint32_t)(w * h), P.taper_task_base = P.taper_pixel * (uint32_t)P.chunks_per_pixel, P.total_tasks = P.taper_task_base;
     P.div_cpp = make_fastdiv((uint32_t)P.chunks_per_pixel), P.div_spp = make_fastdiv((uint32_t)spp), P.div_w = make_fastdiv((uint32_t)w), P.div_tile = make_fastdiv(4u);
     std::vector<uint32_t> cell_start, always;
-    std::vector<uint16_t> cell_prims;
+    std::vector<GridPrim> cell_prims;
     bool grid = false;
     if (mode == 1) {
         GridRec<F> G = {};

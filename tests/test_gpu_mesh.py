@@ -1,0 +1,92 @@
+"""Triangle meshes through the acceleration grid, fp32 included.
+
+fp64: gridded under a PROVEN bound on the residual of the reference's Moeller-Trumbore test (rrtx_grid.h) - images equal
+the list scan's bit for bit (tests/test_gpu_parity.py).  fp32: that bound admits nothing of practical size, and `rrt`
+(use_bvh, the default, as the BVH is the reference's: main.cpp:67) enters triangles into the grid under an EMPIRICAL
+inflation all the same - the stated tolerance of include/rrtx.h (RRTX_FLAG_EXACT_ACCEL): a ray segment may resolve
+differently from the sequential list scan where the ray grazes a triangle's plane, exactly the pairs for which the
+reference's own BVH (boxes without inflation, bvh.h:167-175) differs from its own `-b` scan.  Bounded here:
+  * the VERIFY build re-scans every walked segment sequentially: disagreements <= 1e-5 of the segments (measured: 0 of
+    1.2 M on the 2 880- and 27 072-triangle meshes);
+  * the frame differs from the list scan's (= the oracle's, bit for bit) in <= 1e-4 of its pixels;
+  * against the REAL rrtc in its default BVH mode (its own mt19937 stream, fixture tests/golden/rrtc_mesh_*) the same
+    statistics as for the sphere scenes: mean < 0.1 LSB, RMS < 1.8, 8x8 blocks < 1.5;
+  * `-b` and RRTX_FLAG_EXACT_ACCEL keep the list scan's bits.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from _oracle import GOLDEN, Oracle, mesh_scene
+
+pytestmark = pytest.mark.gpu
+
+VERIFY, EXACT_ACCEL = 32, 64
+
+
+def _render(gpu, path, w, h, spp, fp64=False, **kw):
+    sc = gpu.Scene(path, w, h, fp64=fp64)
+    r = gpu.Rrt(w, h, spp, 50, use_bvh=kw.pop("use_bvh", False), fp64=fp64, **kw)
+    fb = r.render(sc)
+    st = r.stats
+    r.close()
+    return fb, st
+
+
+@pytest.mark.parametrize("nu,nv", [(16, 32), (48, 96)], ids=["2880_triangles", "27072_triangles"])
+def test_fp32_mesh_in_the_grid_within_the_stated_tolerance(gpu, tmp_path, nu, nv):
+    f, n_tri = mesh_scene(tmp_path / "mesh.txt", nu, nv)
+    w, h, spp = 300, 200, 8
+    scan, s0 = _render(gpu, f, w, h, spp)  # -b: the exact list scan
+    assert s0["accel_cells"] == 0 and s0["accel_exact"] == 1
+    grid, s1 = _render(gpu, f, w, h, spp, use_bvh=True)
+    assert s1["accel_cells"] > 0 and s1["accel_exact"] == 0  # gridded, under the approximate rule
+    assert s1["scanned_segments"] < s1["segments"] // 1000
+    differ = (scan != grid).any(axis=2)
+    assert differ.mean() <= 1e-4, int(differ.sum())
+    assert abs(int(s1["segments"]) - int(s0["segments"])) <= 1e-4 * s0["segments"]
+    q0, q1 = gpu.quantise(scan, spp).astype(int), gpu.quantise(grid, spp).astype(int)
+    assert (q0 != q1).mean() <= 1e-4
+    # every walked segment against the sequential scan (VERIFY build of the kernel)
+    _, sv = _render(gpu, f, w, h, 2, use_bvh=True, flags=VERIFY)
+    assert sv["list_mismatches"] <= 1e-5 * sv["segments"], (sv["list_mismatches"], sv["segments"])
+    # the caller who wants the list scan's bits with use_bvh gets them (and pays O(n) per segment)
+    exact, s2 = _render(gpu, f, w, h, spp, use_bvh=True, flags=EXACT_ACCEL)
+    assert s2["accel_exact"] == 1 and np.array_equal(exact, scan)
+    if n_tri < 5000:  # ... which are the oracle's
+        o = Oracle(f, w, h, False)
+        for j in (20, 101, 160):
+            fo, _ = o.render(spp, 50, 1984, order=1, chunk=8, rows=(j, j + 1))
+            assert np.array_equal(scan[j], fo[j]), j
+
+
+def test_fp32_mesh_agrees_statistically_with_the_real_rrtc_bvh(gpu):
+    """The fixture is the REAL rrtc (reference build, its own RNG) in its default BVH mode on tests/golden/scenes/mesh.txt
+    (672 triangles, 3 instances of a UV sphere: lambertian, metal, glass) at 60x40 spp 512."""
+    f = os.path.join(GOLDEN, "scenes", "mesh.txt")
+    ref = np.load(os.path.join(GOLDEN, "rrtc_mesh_60x40_s512.npy")).astype(np.float64)
+    for kw in (dict(use_bvh=True), dict(use_bvh=False)):
+        fb, st = _render(gpu, f, 60, 40, 512, **kw)
+        if kw["use_bvh"]:
+            assert st["accel_cells"] > 0 and st["accel_exact"] == 0
+        d = gpu.quantise(fb, 512).astype(np.float64) - ref
+        assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.1), d.mean(axis=(0, 1))
+        assert np.sqrt((d ** 2).mean()) < 1.8, np.sqrt((d ** 2).mean())
+        blocks = d[:40, :56].reshape(5, 8, 7, 8, 3).mean(axis=(1, 3))
+        assert np.abs(blocks).max() < 1.5, np.abs(blocks).max()
+
+
+def test_a_mesh_beyond_65535_primitives_is_gridded(gpu, tmp_path):
+    # cell lists hold 32-bit primitive indices: 3 x 32 256 triangles + 101 spheres
+    f, n_tri = mesh_scene(tmp_path / "big.txt", 64, 256)
+    assert n_tri > 90000
+    w, h, spp = 96, 64, 2
+    for fp64 in (True, False):
+        scan, s0 = _render(gpu, f, w, h, spp, fp64=fp64)
+        grid, s1 = _render(gpu, f, w, h, spp, fp64=fp64, use_bvh=True)
+        assert s1["accel_cells"] > 0 and s1["accel_exact"] == (1 if fp64 else 0)
+        if fp64:
+            assert np.array_equal(grid, scan)
+        else:
+            assert ((scan != grid).any(axis=2)).mean() <= 1e-3

@@ -486,11 +486,11 @@ def test_accelerated_closest_hit_is_bit_identical(gpu, fp64):
     assert np.array_equal(fb, Oracle(SCENES["final"], w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)[0])
 
 
-def test_a_triangle_mesh_is_gridded_in_fp64_and_scanned_in_fp32(gpu, tmp_path):
+def test_a_triangle_mesh_is_gridded_in_fp64_and_on_request_scanned_in_fp32(gpu, tmp_path):
     """SURVEY.md 8(f) N2.  The bound on Moeller-Trumbore's residual (rrtx_grid.h) admits triangles to the
     grid in fp64 and none of practical size in fp32: the fp64 render walks the grid (cells reported, walk
-    verified against the sequential scan, image equal to the oracle's), the fp32 render of the same file
-    keeps the list scan - and equals the oracle's as well."""
+    verified against the sequential scan, image equal to the oracle's); the fp32 render of the same file
+    keeps the list scan when asked for the list scan's bits (RRTX_FLAG_EXACT_ACCEL) - and equals the oracle's."""
     f, n_tri = mesh_scene(tmp_path / "mesh.txt")
     w, h, spp = 96, 64, 4
     want, stats = Oracle(f, w, h, True).render(spp, 50, 1984, order=1, chunk=8)
@@ -502,8 +502,8 @@ def test_a_triangle_mesh_is_gridded_in_fp64_and_scanned_in_fp32(gpu, tmp_path):
     assert st["list_mismatches"] == 0 and np.array_equal(fb, want)
     assert np.array_equal(_render(gpu, f, w, h, spp, fp64=True)[0], want)  # the list scan
     want32 = Oracle(f, w, h, False).render(spp, 50, 1984, order=1, chunk=8)[0]
-    fb, st = _render(gpu, f, w, h, spp, use_bvh=True)
-    assert st["accel_cells"] == 0 and np.array_equal(fb, want32)
+    fb, st = _render(gpu, f, w, h, spp, use_bvh=True, flags=64)  # RRTX_FLAG_EXACT_ACCEL (without it: tests/test_gpu_mesh.py)
+    assert st["accel_cells"] == 0 and st["accel_exact"] == 1 and np.array_equal(fb, want32)
     # camera rays longer than the |d| the inflation is proven for (focus distance 4000: |d| ~ 4000) take the list scan
     f2, _ = mesh_scene(tmp_path / "mesh_far_focus.txt", camera="camera 6 2.5 7 0 0.8 0 0 1 0 35 0.0 4000")
     want2, stats2 = Oracle(f2, 64, 40, True).render(2, 50, 1984, order=1, chunk=2)

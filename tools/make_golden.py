@@ -81,5 +81,25 @@ def main():
         print("rrtc", name, img.mean())
 
 
+def mesh_fixture():
+    """6. a triangle mesh (our own scene, tests/_oracle.py:mesh_scene) through the real rrtc in its DEFAULT mode, the BVH
+    (main.cpp:67, bvh.h:167-175): the statistical target for `rrt` on fp32 meshes, which enters them into its grid
+    under the approximate rule (include/rrtx.h, RRTX_FLAG_EXACT_ACCEL)."""
+    from _oracle import mesh_scene
+
+    f, n_tri = mesh_scene(os.path.join(GOLDEN, "scenes", "mesh.txt"), 8, 16)
+    w, h, spp = 60, 40, 512
+    out = subprocess.run([os.path.join(REF_DIR, "rrtc"), "-i", f, "-w", str(w), "-h", str(h), "-s", str(spp)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    tok = out.split()
+    assert tok[0] == b"P3" and int(tok[1]) == w and int(tok[2]) == h
+    img = np.array([int(x) for x in tok[4:]], dtype=np.uint8).reshape(h, w, 3)
+    np.save(os.path.join(GOLDEN, "rrtc_mesh_%dx%d_s%d.npy" % (w, h, spp)), img)
+    print("rrtc mesh (%d triangles, BVH)" % n_tri, img.mean())
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["mesh"]:
+        mesh_fixture()
+    else:
+        main()
+        mesh_fixture()
