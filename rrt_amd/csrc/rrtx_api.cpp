@@ -356,10 +356,18 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
         chunk = p.samples_per_pixel;
     else if (chunk == 0) {
         chunk = p.samples_per_pixel > 8 ? 8 : p.samples_per_pixel;
-        // keep the partial buffer of a full frame under 2 GiB and the task count under 2^31
+        // 8 samples per work item; 16 once the FULL frame's partial sums (3 values per item) pass 2 GiB - per-item costs
+        // (hand-out, decoding, the 12-byte store) then outweigh what shorter items save; more only where the items could
+        // not be counted in 31 bits or their sums would pass 48 GiB, a sixth of one MI355X's HBM.  Long items cost at the
+        // END of a launch, where every lane holds half an item when the queue runs dry: one of the 8 shards of the
+        // 3840x2160 spp 1000 frame takes 207 ms with 128 samples per item (what the old rule - 2 GiB at most - chose),
+        // 165 with 8 or 16, against 160 for an eighth of the frame; the full frame on one GPU: 1299 / 1292 / 1281 ms with
+        // 8 / 16 / 128 (use_bvh: 684 / 657 / 641).  A function of (w, h, spp) only: the same bits on any number of GPUs.
         for (;;) {
-            int64_t cpp = (p.samples_per_pixel + chunk - 1) / chunk;
-            if (pixels_full * cpp * 3 * 8 <= ((int64_t)1 << 31) || chunk >= p.samples_per_pixel) break;
+            const int64_t cpp = (p.samples_per_pixel + chunk - 1) / chunk;
+            const int64_t bytes = pixels_full * cpp * 3 * 8;
+            const bool fits = pixels_full * cpp < ((int64_t)1 << 31) - (1 << 20) && bytes <= ((int64_t)48 << 30);
+            if ((fits && (bytes <= ((int64_t)2 << 30) || chunk >= 16)) || chunk >= p.samples_per_pixel) break;
             chunk *= 2;
         }
         if (chunk > p.samples_per_pixel) chunk = p.samples_per_pixel;

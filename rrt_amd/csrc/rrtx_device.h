@@ -48,7 +48,7 @@ constexpr int kPlistCap = 15;    // sphere indices per pixel in the camera-ray c
 constexpr int kPlistStride = 16; // ... stored as uint16 [count | 0xFFFF, idx...]: 32 bytes per pixel
 constexpr int kListPasses = 3;   // LIST passes allowed between two SCAN passes (measured: 1 -> 80.9, 2 -> 79.8, 3 -> 79.0, 6 -> 78.7 ms)
 constexpr int kTailSplit = 8;    // a parked item is finished as up to this many independent units (3 bits in tail_units)
-constexpr int kHandoffIters = 8; // ... and after this many iterations past queue-dry regardless of the lane count
+constexpr int kHandoffIters = 12; // ... and after this many iterations past queue-dry regardless of the lane count (final.txt 1200x800, 8 / 12 / 16 / 24: spp 8 3.28 / 3.12 / 2.98 / 2.85 ms, an eighth of the spp 500 frame 11.42 / 11.30 / 11.32 / 11.38, the whole of it 77.5 / 77.6 / 77.7 / 78.0)
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
     F cx, cy, cz, r2;

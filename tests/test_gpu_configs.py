@@ -6,8 +6,8 @@
     C4  scenes/final.txt  1200x800  spp 500   fp64   (rrtd)
     C5  scenes/final.txt  3840x2160 spp 1000  fp32   row-tile shards over 8 GPUs
 
-The sample count changes what a small-spp test never reaches: `sample_chunk` (8 at spp 500, 128 for the 4K
-frame), the number of work items (60 M / 66 M), the 32-bit task and unit encodings, the population that is
+The sample count changes what a small-spp test never reaches: `sample_chunk` (8 at spp 500, 16 for the 4K
+frame), the number of work items (60 M / 523 M), the 32-bit task and unit encodings, the population that is
 handed off at the end of a launch.  So each configuration is rendered in full, whole rows are compared with
 the oracle BIT FOR BIT (zero tolerance, same summation shape), the accelerated closest hit (`use_bvh`, the
 CLI's default) must give the same frame, and the 8-way row-tile decomposition - executed shard after shard on
@@ -110,7 +110,7 @@ def test_config5_final_3840x2160_spp1000_as_8_shards(gpu):
     w, h, spp = 3840, 2160, 1000
     full, st = _render(gpu, FINAL, w, h, spp)
     chunk = st["sample_chunk"]
-    assert chunk == 128, chunk  # the per-task partial sums of the FULL frame stay under 2 GiB (rrtx_create)
+    assert chunk == 16, chunk  # 8 samples per work item, 16 once the full frame's partial sums pass 2 GiB (rrtx_create)
     cpp = (spp + chunk - 1) // chunk
     assert w * h * cpp < 2 ** 31 and st["samples"] == w * h * spp
     assert 2.47 < st["segments"] / st["samples"] < 2.52  # (16:9 here against 3:2 in C3: more sky in the frame, 2.4935)
