@@ -307,6 +307,12 @@ def main():
         return reduce_max(time.perf_counter() - t0), sr.rrt.collect()
 
     sr = ShardedRenderer(SCENE, W, H, spp, DEPTH, fp64=False, tile_rows=args.tile_rows, device=dev, collect_stats=True)
+    if world > 1:
+        # RCCL sets its point-to-point channels up at their first use: one untimed exchange of a few bytes, so that not
+        # even a run with --warmup 0 times connection set-up instead of the gather
+        tiny = torch.zeros(8, dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
+        dist.gather(tiny, gather_list=[torch.zeros_like(tiny) for _ in range(world)] if rank == 0 else None, dst=0)
+        barrier()
     elapsed, st = timed(sr, args.steps, args.warmup)
     kernel_only = None
     if world > 1:  # the same steps without the gather: what the exchange adds
