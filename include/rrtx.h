@@ -161,6 +161,10 @@ typedef struct rrtx_params {
  * spheres, moving spheres and fp64 meshes are always under the proven rule.  With this flag fp32 triangles stay
  * outside the grid (always-list of <= 48, else the whole scene is scanned: O(n) per segment). */
 #define RRTX_FLAG_EXACT_ACCEL 64
+/* List scan (use_bvh = 0): finish the paths a launch parks at its end with the tail kernel (8 lanes per ray on the
+ * list) instead of a resume pass through the acceleration grid (A/B switch; the images are identical - the grid is
+ * only used for this where it is proven to reproduce the scan bit for bit). */
+#define RRTX_FLAG_NO_TAIL_GRID 128
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST

@@ -77,6 +77,7 @@ struct rrtx_ctx {
     uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
     // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
     bool accel = false;
+    bool tail_grid = false;   // list scan (-b), but what a launch parks at its end is finished through the grid (a RESUME pass: same bits)
     uint32_t *d_grid_cell_start = nullptr, *d_grid_always = nullptr;
     GridPrim *d_grid_cell_prims = nullptr;
     bool accel_exact = true; // the grid is proven to reproduce the list scan bit for bit (false: fp32 triangles gridded under the approximate rule)
@@ -91,6 +92,7 @@ struct rrtx_ctx {
     size_t tail_capacity = 0;
     int handoff_lanes = kHandoffLanes;
     int tail_blocks = 0;
+    int resume_blocks = 0;    // grid of the resume pass (= the render grid in the accelerated mode; its own occupancy after a list-scan render)
     void *d_rows = nullptr;    // own output buffer for the host-pointer API
     // timing
     hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
@@ -160,8 +162,11 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     for (void *p : {(void *)c->d_grid_cell_start, (void *)c->d_grid_cell_prims, (void *)c->d_grid_always})
         if (p) (void)hipFree(p);
     c->d_grid_cell_start = c->d_grid_always = nullptr, c->d_grid_cell_prims = nullptr;
-    c->accel = false;
-    if (c->p.use_bvh && c->tail_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN)) {
+    c->accel = false, c->tail_grid = false;
+    // (also without use_bvh: the paths a list-scan launch parks at its end - half a percent of its segments - are then
+    // finished lane per ray through the grid instead of 8 lanes per ray on the list: 0.75 against 1.25 ms for an eighth of the
+    // spp 500 frame, and the same bits - only where the grid is PROVEN to give them; RRTX_FLAG_NO_TAIL_GRID: A/B switch)
+    if (c->tail_ok && !(c->p.flags & RRTX_FLAG_EXACT_SCAN) && (c->p.use_bvh || !(c->p.flags & (RRTX_FLAG_NO_TAIL_GRID | RRTX_FLAG_NO_TAIL_KERNEL | RRTX_FLAG_VERIFY_LISTS)))) {
         std::vector<uint32_t> cell_start, always;
         std::vector<GridPrim> cell_prims;
         GridRec<F> G = {};
@@ -171,8 +176,8 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         // under an empirical inflation, unless the caller insists on the list scan's bits (RRTX_FLAG_EXACT_ACCEL): the
         // reference's own default, its BVH, has the same hazard band against its own list scan (bvh.h:167-175)
         bool approximate = false;
-        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G, !(c->p.flags & RRTX_FLAG_EXACT_ACCEL),
-                          &approximate)) {
+        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G,
+                          c->p.use_bvh && !(c->p.flags & RRTX_FLAG_EXACT_ACCEL), &approximate)) {
             c->accel_exact = !approximate;
             if (cell_prims.empty()) cell_prims.push_back(0);
             if (always.empty()) always.push_back(0), c->n_always = 0;
@@ -183,7 +188,8 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             c->n_grid_cells = (int)cell_start.size() - 1;
             c->n_grid_prims = (int)cell_start.back();
             memcpy(c->grid_bytes, &G, sizeof G);
-            c->accel = true;
+            c->accel = c->p.use_bvh != 0;
+            c->tail_grid = !c->accel;
         }
     }
     c->n_sph = s->num_spheres;
@@ -195,7 +201,8 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     return RRTX_OK;
 }
 
-template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
+// with_grid: the acceleration grid's tables go along (accelerated render and resume passes; a list-scan render takes none)
+template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, bool with_grid)
 {
     KernelParams<F> P = {};
     P.sph_hot = (const SphereHot<F> *)c->d_hot;
@@ -226,7 +233,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out)
     P.tail_items = (TailItem<F> *)c->d_tail_items;
     P.tail_rad = (F *)c->d_tail_rad;
     P.tail_units = c->d_tail_units;
-    if (c->accel) {
+    if (with_grid && (c->accel || c->tail_grid)) {
         P.grid_cell_start = c->d_grid_cell_start, P.grid_cell_prims = c->d_grid_cell_prims, P.grid_always = c->d_grid_always;
         P.n_always = c->n_always, P.n_grid_cells = c->n_grid_cells, P.n_grid_prims = c->n_grid_prims;
         memcpy(&P.grid, c->grid_bytes, sizeof(GridRec<F>));
@@ -465,7 +472,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     // persistent grid: fill the chip once with the kernel variant this scene selects; never more
     // blocks than there are task batches
     int bpc = 0;
-    RRTX_HIP(c->p.fp64 ? render_occupancy<double>(make_params<double>(c, nullptr), c->use_filter, c->lds_mode, &bpc) : render_occupancy<float>(make_params<float>(c, nullptr), c->use_filter, c->lds_mode, &bpc));
+    RRTX_HIP(c->p.fp64 ? render_occupancy<double>(make_params<double>(c, nullptr, c->accel), c->use_filter, c->lds_mode, &bpc) : render_occupancy<float>(make_params<float>(c, nullptr, c->accel), c->use_filter, c->lds_mode, &bpc));
     c->blocks_per_cu = bpc < 1 ? 1 : bpc;
     int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
     const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
@@ -486,11 +493,11 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         RRTX_HIP(hipMalloc((void **)&pl, bytes));
         c->d_plist = pl; // owned by the context from here on: a failing launch below must not leak it
         if (c->p.fp64) {
-            KernelParams<double> P = make_params<double>(c, nullptr);
+            KernelParams<double> P = make_params<double>(c, nullptr, c->accel);
             RRTX_HIP(launch_primary_lists<double>(P, pl, c->stream));
         }
         else {
-            KernelParams<float> P = make_params<float>(c, nullptr);
+            KernelParams<float> P = make_params<float>(c, nullptr, c->accel);
             RRTX_HIP(launch_primary_lists<float>(P, pl, c->stream));
         }
         RRTX_HIP(hipStreamSynchronize(c->stream));
@@ -520,6 +527,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         const int64_t cap = (int64_t)c->num_cus * 8;
         c->tail_blocks = (int)(tb < cap ? tb : cap);
         if (c->tail_blocks < 1) c->tail_blocks = 1;
+        c->resume_blocks = c->grid_blocks; // (persistent waves pulling units: blocks beyond what is resident just find the queue empty)
     }
     return RRTX_OK;
 }
@@ -552,15 +560,25 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     void *out = c->use_partial ? c->d_partial : d_rows;
     const FinalizeShape shape = {(uint32_t)((size_t)c->local_rows * c->p.image_width), c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel};
     if (c->p.fp64) {
-        KernelParams<double> P = make_params<double>(c, out);
+        KernelParams<double> P = make_params<double>(c, out, c->accel);
         RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(c->accel ? launch_resume<double>(P, c->use_filter, c->grid_blocks, st) : launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
+        if (c->tail_capacity) {
+            if (c->accel || c->tail_grid)
+                RRTX_HIP(launch_resume<double>(make_params<double>(c, out, true), c->use_filter, c->resume_blocks, st));
+            else
+                RRTX_HIP(launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
+        }
         if (c->use_partial) RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, shape, st));
     }
     else {
-        KernelParams<float> P = make_params<float>(c, out);
+        KernelParams<float> P = make_params<float>(c, out, c->accel);
         RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) RRTX_HIP(c->accel ? launch_resume<float>(P, c->use_filter, c->grid_blocks, st) : launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
+        if (c->tail_capacity) {
+            if (c->accel || c->tail_grid)
+                RRTX_HIP(launch_resume<float>(make_params<float>(c, out, true), c->use_filter, c->resume_blocks, st));
+            else
+                RRTX_HIP(launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
+        }
         if (c->use_partial) RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, shape, st));
     }
     RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));

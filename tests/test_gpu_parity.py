@@ -272,12 +272,13 @@ def test_cli_renders_a_batch_of_scenes_in_one_process(gpu, tmp_path):
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
 def test_scan_variants_are_bit_identical(gpu, fp64):
     # flags: 1 exact scan (reference discriminant in phase 1), 2 filter + scalar loads only, 0 default
-    # (hybrid scalar/LDS for fp32, scalar for fp64), 4 filter + LDS only, 8 no tail kernel
+    # (hybrid scalar/LDS for fp32, scalar for fp64), 4 filter + LDS only, 8 no tail kernel, 128 the end of the launch
+    # through the tail kernel instead of a resume pass on the grid
     w, h, spp = 96, 64, 6
     o = Oracle(SCENES["final"], w, h, fp64)
     want, so = o.render(spp, 50, 1984, order=1)
     sc = gpu.Scene(SCENES["final"], w, h, fp64=fp64)
-    for flags in (1, 2, 0, 4, 8, 1 | 8, 4 | 8):
+    for flags in (1, 2, 0, 4, 8, 1 | 8, 4 | 8, 128, 2 | 128, 4 | 128):
         r = _list_rrt(gpu, w, h, spp, 50, fp64=fp64, sample_chunk=-1, flags=flags)
         fb = r.render(sc)
         assert np.array_equal(fb, want), "flags=%d" % flags
@@ -290,10 +291,11 @@ def test_hand_off_thresholds_do_not_change_the_image(gpu):
     w, h, spp = 200, 120, 24  # enough work for the queue to matter, small enough for the oracle
     want, _ = Oracle(SCENES["final"], w, h, False).render(spp, 50, 1984, order=1, chunk=8)
     sc = gpu.Scene(SCENES["final"], w, h)
-    for lanes, iters in ((1, 1), (7, 8), (64, 1), (32, 1000)):
-        r = _list_rrt(gpu, w, h, spp, 50, handoff_lanes=lanes, handoff_iters=iters)
-        assert np.array_equal(r.render(sc), want), (lanes, iters)
-        r.close()
+    for flags in (0, 128):  # the parked work finished by a resume pass on the grid / by the tail kernel
+        for lanes, iters in ((1, 1), (7, 8), (64, 1), (32, 1000)):
+            r = _list_rrt(gpu, w, h, spp, 50, handoff_lanes=lanes, handoff_iters=iters, flags=flags)
+            assert np.array_equal(r.render(sc), want), (flags, lanes, iters)
+            r.close()
 
 
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
