@@ -554,7 +554,11 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     }
     if (c->total_tasks == 0) return RRTX_OK;
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 256, st)); // task cursor, parked-item count, tail cursor, unit count; queue-over flag
+#ifdef RRTX_SECTION_DIAG
+    RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 256, st));
+#else
     if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 32, st));
+#endif
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->use_partial ? c->d_partial : d_rows;
@@ -594,6 +598,15 @@ extern "C" int rrtx_diag_read(rrtx_ctx *c, void *dst)
     RRTX_HIP(hipDeviceSynchronize());
     RRTX_HIP(hipMemcpy(dst, c->d_diag, (size_t)131072 * 64, hipMemcpyDeviceToHost));
     RRTX_HIP(hipMemset(c->d_diag, 0, (size_t)131072 * 64));
+    return 0;
+}
+#endif
+
+#ifdef RRTX_SECTION_DIAG
+extern "C" int rrtx_section_diag(rrtx_ctx *c, unsigned long long out[8]) // developer builds: a wave's clock cycles per section of the render loop, summed over the waves
+{
+    RRTX_HIP(hipDeviceSynchronize());
+    RRTX_HIP(hipMemcpy(out, c->d_counters + 16, 64, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

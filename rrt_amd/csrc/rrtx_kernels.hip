@@ -280,7 +280,20 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     unsigned long long diag_pull_t = 0;
 #endif
 
+#ifdef RRTX_SECTION_DIAG // developer builds: clock cycles of a wave per section of the loop -> counters[16 + k]
+    unsigned long long sec_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sec_t = __builtin_amdgcn_s_memtime();
+    int sec_cur = 0;
+#define RRTX_SEC(k)                                                                                                                        \
+    do {                                                                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                                  \
+        sec_cycles[sec_cur] += now_ - sec_t;                                                                                           \
+        sec_t = now_, sec_cur = (k);                                                                                                   \
+    } while (0)
+#else
+#define RRTX_SEC(k) ((void)0)
+#endif
     for (;;) {
+        RRTX_SEC(0); // hand-out, polling, hand-off
 #ifdef RRTX_DIAG
         diag_iters += 1;
         if (queue_over) {
@@ -451,6 +464,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             }
         }
 
+        RRTX_SEC(1); // camera rays
         if (alive && need_ray) {
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
             need_ray = false;
@@ -469,6 +483,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // at most `list_passes` such passes (sky hits regenerate, so a lane may need several) a SCAN pass
         // runs the 488-sphere scan for every lane, by then almost all on secondary rays.  Every segment
         // is still intersected exactly once with the exact test in primitive order: same image.
+        RRTX_SEC(2); // camera-ray lists (LIST passes) / walk
         const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0 && !(ACCEL != 0 && in_walk);
         const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
         list_passes_done = list_pass ? list_passes_done + 1 : 0;
@@ -572,11 +587,13 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 }
             }
             if (need_scan) {
+            RRTX_SEC(3); // scan phase 1 (filter + pushes; the drains in between go to section 4)
             n_scanned += 1;
             uint32_t cnt = 0;
 
             // phase 2 body, used for flushes and at the end
             auto drain = [&]() {
+                RRTX_SEC(4); // phase 2: exact refinement of the candidates
                 n_candidates += cnt;
                 for (uint32_t s = 0; s < cnt; ++s) {
                     const int k = (int)my_cand[s * 64];
@@ -600,6 +617,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     }
                 }
                 cnt = 0;
+                RRTX_SEC(3);
             };
 
             // phase 1a: spheres, wave-uniform scalar loads.  The block of kUnroll tests is kept
@@ -716,9 +734,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             } // scan pass
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
+            RRTX_SEC(5); // shading
             if (!still_walking) done = shade<F>(P, best, path, rng, radiance);
             } // max_depth > 0
 
+            RRTX_SEC(6); // sample / task bookkeeping, stores
             if (done) {
                 acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
                 s_cur += 1;
@@ -740,6 +760,12 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
         atomicAdd(&P.counters[3], (unsigned long long)n_scanned);
     }
+#ifdef RRTX_SECTION_DIAG
+    RRTX_SEC(7);
+    if (lane == 0 && !RESUME)
+        for (int k = 0; k < 8; ++k) atomicAdd(&P.counters[16 + k], sec_cycles[k]);
+#endif
+#undef RRTX_SEC
 #ifdef RRTX_DIAG
     if (lane == 0 && !RESUME) {
         const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
