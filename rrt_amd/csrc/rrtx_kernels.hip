@@ -1178,8 +1178,9 @@ template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(con
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
         F s = 0;
         if (v < n_chunked) {
-            const F *p = partial + v;
-            for (int c = 0; c < S.chunks_per_pixel; ++c) s = s + p[(size_t)c * n_chunked];
+            const uint32_t q = v / 3u, ch = v - q * 3u;
+            const F *p = partial + (size_t)q * (size_t)S.chunks_per_pixel * 3 + ch; // [pixel][chunk][3], see task_slot
+            for (int c = 0; c < S.chunks_per_pixel; ++c) s = s + p[(size_t)c * 3];
         }
         else {
             // the sums a chunk task would have formed: 0 + s0 + s1 + ... per chunk, then chunk by chunk
