@@ -258,7 +258,7 @@ void free_scene_buffers(rrtx_ctx *c)
         *b = nullptr;
     }
     c->have_scene = false;
-    c->accel = false;
+    c->accel = c->tail_grid = false;
     c->tail_capacity = 0;
 }
 

@@ -150,14 +150,21 @@ int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, 
     const ncclDataType_t dtype = g->p.fp64 ? ncclDouble : ncclFloat;
     if (!g->rehearsal) {
         GRP_NCCL(g, g->rccl->GroupStart());
-        for (int r = 0; r < g->n; ++r) {
+        ncclResult_t bad = ncclSuccess; // (a group that was started is always ended, also when a call inside it fails)
+        const char *where = "";
+        for (int r = 0; r < g->n && bad == ncclSuccess; ++r) {
             if (g->rows[r] == 0) continue;
             const size_t count = (size_t)g->rows[r] * g->p.image_width * 3;
             // (rank 0 sends to itself like everyone else: one code path for every N, N = 1 included)
-            GRP_NCCL(g, g->rccl->Send(g->d_local[r], count, dtype, 0, g->comms[r], (hipStream_t)rrtx_stream(g->ctx[r])));
-            GRP_NCCL(g, g->rccl->Recv((unsigned char *)g->d_gathered + (size_t)g->row_off[r] * row_bytes, count, dtype, r, g->comms[0], s0));
+            bad = g->rccl->Send(g->d_local[r], count, dtype, 0, g->comms[r], (hipStream_t)rrtx_stream(g->ctx[r]));
+            where = "ncclSend";
+            if (bad != ncclSuccess) break;
+            bad = g->rccl->Recv((unsigned char *)g->d_gathered + (size_t)g->row_off[r] * row_bytes, count, dtype, r, g->comms[0], s0);
+            where = "ncclRecv";
         }
-        GRP_NCCL(g, g->rccl->GroupEnd());
+        const ncclResult_t ended = g->rccl->GroupEnd();
+        if (bad == ncclSuccess && ended != ncclSuccess) bad = ended, where = "ncclGroupEnd";
+        if (bad != ncclSuccess) return set_error(RRTX_E_DEVICE, std::string("RCCL error in ") + where + ": " + g->rccl->GetErrorString(bad));
     }
     else {
         for (int r = 0; r < g->n; ++r) {

@@ -75,6 +75,14 @@ def test_no_silent_fallback_without_a_gpu():
     exe = os.path.join(ROOT, "rrt")
     r = subprocess.run([exe, "-i", os.path.join(ROOT, "scenes", "test1.txt"), "-w", "16", "-h", "16", "-s", "1"], capture_output=True)
     assert r.returncode == 99 and b"HIP error" in r.stderr and r.stdout == b""
+    # several devices (-G): the same loud failure, and a bad -D ends the run while the flags are parsed (main.cpp:107-110)
+    r = subprocess.run([exe, "-G", "2", "-i", os.path.join(ROOT, "scenes", "test1.txt"), "-w", "16", "-h", "16", "-s", "1"], capture_output=True)
+    assert r.returncode == 99 and b"HIP error" in r.stderr and r.stdout == b""
+    r = subprocess.run([exe, "-D", "3", "-i", "/nonexistent/scene.txt"], capture_output=True)
+    assert r.returncode == 99  # (not 2: the device is selected before the scene is opened)
+    with pytest.raises(rrt_amd.RrtxError) as e:
+        rrt_amd.RrtGroup(2, 16, 16, 1, 5)
+    assert e.value.code == -2
 
 
 def test_product_does_not_reference_the_oracle():
