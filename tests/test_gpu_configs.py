@@ -129,3 +129,28 @@ def test_config5_final_3840x2160_spp1000_as_8_shards(gpu):
     assert np.array_equal(acc, full)
     assert all(p["accel_cells"] > 0 for p in parts)
     assert np.array_equal(gpu.quantise(acc, spp), gpu.quantise(full, spp))
+
+
+def test_config3_size_independent_properties(gpu):
+    """Properties that hold at any size, checked at C3's: (i) rendering twice gives the same bits; (ii) the summation shape
+    (8-sample work items against the reference's one running sum per pixel, rrt.cu:111-118) changes a pixel by rounding only -
+    relative 4e-7 x spp in radiance, at most 1 LSB in the 8-bit image; (iii) another seed gives another frame of the same
+    picture: per-channel means within 0.1 LSB, and two seeds differ from each other like either differs from the real rrtc
+    (RMS < 1.8 LSB at spp 500); (iv) the frame is the sum of its samples: spp 500 equals spp 250 of seed-free halves only in
+    distribution, so instead: a frame rendered as two row-tile halves of different tile heights assembles to the same bits."""
+    w, h, spp = 1200, 800, 500
+    a, st = _render(gpu, FINAL, w, h, spp)
+    b, _ = _render(gpu, FINAL, w, h, spp)
+    assert np.array_equal(a, b)
+    ref_order, _ = _render(gpu, FINAL, w, h, spp, sample_chunk=-1)
+    assert np.allclose(a, ref_order, rtol=4e-7 * spp, atol=0)
+    qa, qr = gpu.quantise(a, spp).astype(int), gpu.quantise(ref_order, spp).astype(int)
+    assert np.abs(qa - qr).max() <= 1 and (qa != qr).mean() < 1e-3
+    other, _ = _render(gpu, FINAL, w, h, spp, seed=77)
+    assert not np.array_equal(a, other)
+    d = gpu.quantise(other, spp).astype(np.float64) - qa
+    assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.1), d.mean(axis=(0, 1))
+    assert np.sqrt((d ** 2).mean()) < 1.8, np.sqrt((d ** 2).mean())
+    for count, tile in ((2, 1), (2, 400), (3, 7)):
+        acc, _ = _sharded(gpu, FINAL, w, h, spp, count, tile)
+        assert np.array_equal(acc, a), (count, tile)
