@@ -126,8 +126,12 @@ struct Worker {
     std::vector<int32_t> group_devices;
     rrtx_ctx *ctx = nullptr;
     rrtx_group *group = nullptr;
-    std::shared_ptr<std::vector<fp_t>> frames[2]; // page-locked once, used in turn
-    std::future<int> writer;                       // the previous scene's quantise + encode, running beside this scene's render
+    // kWriters + 1 frame buffers, page-locked once and used in turn, and up to kWriters writer tasks (quantise + encode +
+    // write) in flight beside this scene's render: a noisy 1280x720 PNG takes ~6.5 ms of wall time however many threads
+    // deflate it, a render at the reference's animation settings 5.2 ms - with ONE writer the batch ran at the writer's pace
+    static constexpr int kWriters = 2;
+    std::shared_ptr<std::vector<fp_t>> frames[kWriters + 1];
+    std::future<int> writers[kWriters]; // writers[k % kWriters] works on frames[k % (kWriters + 1)]
     size_t rendered = 0;
 
     void log(const std::string &text)
@@ -145,21 +149,46 @@ struct Worker {
         std::fflush(stdout);
         std::_Exit(99);
     }
-    void finish_writer()
+    void finish_writer(std::future<int> &w)
     {
-        if (writer.valid() && writer.get()) shared->exit_code = 1;
+        if (w.valid() && w.get()) shared->exit_code = 1;
+    }
+
+    // A scene file parsed (scene.h:212-452 -> rrtx_scene_load), with what the reference would have exited with had it failed
+    struct Parsed {
+        rrtx_scene *scene = nullptr;
+        int rc = 0, exit_code = 0;
+    };
+    Parsed parse(const Job &job) const
+    {
+        Parsed p;
+        p.rc = rrtx_scene_load(job.scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &p.scene);
+        if (p.rc) p.exit_code = rrtx_scene_exit_code(); // (thread-local: read on the thread that parsed)
+        return p;
     }
 
     void run()
     {
+        // the NEXT scene of this worker is parsed by a helper thread while the current one renders (0.4 ms of a 5.2 ms frame at
+        // the reference's animation settings): a worker therefore holds one job in reserve
         const std::vector<Job> &jobs = *shared->jobs;
-        for (;;) {
-            if (shared->stop) break;
-            const size_t k = shared->next_job.fetch_add(1);
-            if (k >= jobs.size()) break;
-            render_job(jobs[k]);
+        size_t cur = shared->next_job.fetch_add(1);
+        Parsed cur_scene;
+        if (cur < jobs.size()) cur_scene = parse(jobs[cur]);
+        while (cur < jobs.size()) {
+            const size_t nxt = shared->stop ? jobs.size() : shared->next_job.fetch_add(1);
+            std::future<Parsed> ahead;
+            if (nxt < jobs.size()) ahead = std::async(std::launch::async, [this, &jobs, nxt]() { return parse(jobs[nxt]); });
+            if (shared->stop) { // a scene elsewhere did not parse: nothing further is started (what is in flight is written)
+                skip_output_turn(jobs[cur]);
+                if (cur_scene.scene) rrtx_scene_free(cur_scene.scene);
+            }
+            else
+                render_job(jobs[cur], cur_scene);
+            cur = nxt;
+            cur_scene = ahead.valid() ? ahead.get() : Parsed();
         }
-        finish_writer();
+        for (auto &w : writers) finish_writer(w);
         for (auto &f : frames)
             if (f) (void)rrtx_unpin_host(f->data());
         if (ctx) rrtx_destroy(ctx);
@@ -176,15 +205,15 @@ struct Worker {
         shared->out_cv.notify_all();
     }
 
-    void render_job(const Job &job)
+    void render_job(const Job &job, const Parsed &parsed)
     {
         std::ostringstream err; // this job's stderr chatter
-        rrtx_scene *scene = nullptr;
-        int rc = rrtx_scene_load(job.scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &scene);
+        rrtx_scene *scene = parsed.scene;
+        int rc = parsed.rc;
         if (rc) {
             // the reference exits on the spot with scene.h's code (1 obj errors, 2 cannot open, 3 unknown material, 4 sanity);
             // in a batch: no further scenes are started, what is in flight is written, the first such code is the exit code
-            int code = rrtx_scene_exit_code();
+            int code = parsed.exit_code;
             int expected = 0;
             shared->exit_code.compare_exchange_strong(expected, code ? code : 1);
             shared->stop = true;
@@ -227,15 +256,17 @@ struct Worker {
         }
         if (rc) die(rc, err.str());
 
-        // two frame buffers, used in turn: one is being quantised and encoded by the writer task while the next
-        // scene renders into the other (allocating and zero-filling 11 MB per frame cost more than a short render)
-        std::shared_ptr<std::vector<fp_t>> &slot = frames[rendered & 1];
+        // frame buffers used in turn: while this scene renders into one, writer tasks quantise and encode the previous ones
+        // (allocating and zero-filling 11 MB per frame cost more than a short render)
+        const size_t turn = rendered;
         rendered += 1;
+        // (the buffer of this turn was last read by the writer of turn - (kWriters + 1), whose slot, (turn - 1) % kWriters, was
+        // joined when the writer of turn - 1 took it over: nothing to wait for here)
+        std::shared_ptr<std::vector<fp_t>> &slot = frames[turn % (kWriters + 1)];
         if (!slot) {
             slot = std::make_shared<std::vector<fp_t>>((size_t)prm.image_width * prm.image_height * 3, (fp_t)0);
             (void)rrtx_pin_host(slot->data(), slot->size() * sizeof(fp_t)); // (best effort: unpinned it is only slower)
         }
-        // (the writer still in flight works on the OTHER buffer: the one that used this buffer was joined before that one started)
         auto fb = slot;
         // rrt.cu:195-202,261
         err << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
@@ -286,7 +317,8 @@ struct Worker {
         log(err.str());
 
         // main.cpp:140-162: quantise, flip, write - off the render path: it overlaps this worker's next scene
-        finish_writer();
+        std::future<int> &writer = writers[turn % kWriters];
+        finish_writer(writer); // (the task of kWriters turns ago)
         const int w = prm.image_width, h = prm.image_height, spp = prm.samples_per_pixel;
         Shared *sh = shared;
         const Job *jp = &job;

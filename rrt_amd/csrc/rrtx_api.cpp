@@ -75,6 +75,7 @@ struct rrtx_ctx {
     unsigned long long *d_counters = nullptr;
     void *d_partial = nullptr; // [total_tasks][3] unless every pixel is a single task
     uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
+    bool have_plist = false;      // ... valid for the current scene (the buffer itself is kept from scene to scene)
     // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
     bool accel = false;
     bool tail_grid = false;   // list scan (-b), but what a launch parks at its end is finished through the grid (a RESUME pass: same bits)
@@ -94,6 +95,7 @@ struct rrtx_ctx {
     int tail_blocks = 0;
     int resume_blocks = 0;    // grid of the resume pass (= the render grid in the accelerated mode; its own occupancy after a list-scan render)
     void *d_rows = nullptr;    // own output buffer for the host-pointer API
+    std::vector<std::pair<void **, size_t>> caps; // capacities of the per-scene device buffers (see ensure_buffer)
     // timing
     hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
     int ev_pending = 0;
@@ -119,6 +121,27 @@ int rows_of_shard(const rrtx_params &p, std::vector<int32_t> *out)
     return count;
 }
 
+// The per-scene device buffers (tables, grid, camera-ray lists, parked-item buffers: 200 MB at 1280x720) survive from scene
+// to scene and are reallocated only when one has to grow: a batch of frames used to pay ~15 hipMalloc / hipFree pairs per
+// scene (0.97 ms per rrtx_set_scene, of a 5.2 ms render at the reference's animation settings).
+int ensure_buffer(rrtx_ctx *c, void **slot, size_t bytes)
+{
+    size_t *cap = nullptr;
+    for (auto &e : c->caps)
+        if (e.first == slot) cap = &e.second;
+    if (!cap) {
+        c->caps.push_back({slot, 0});
+        cap = &c->caps.back().second;
+    }
+    if (*slot && *cap >= bytes) return RRTX_OK;
+    if (*slot) (void)hipFree(*slot);
+    *slot = nullptr, *cap = 0;
+    const size_t want = bytes + bytes / 4 + 256; // (room to grow: the next frame of an animation has a few primitives more or less)
+    RRTX_HIP(hipMalloc(slot, want));
+    *cap = want;
+    return RRTX_OK;
+}
+
 template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
 {
     PackedScene<F> packed;
@@ -134,15 +157,11 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     const bool filter_ok = packed.filter_ok;
 
     RRTX_HIP(hipSetDevice(c->device));
-    void *old[7] = {c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat};
-    for (void *p : old)
-        if (p) (void)hipFree(p);
-    c->d_hot = c->d_filter = c->d_cold = c->d_msph = c->d_tri = c->d_tri_scan = c->d_mat = nullptr;
     c->have_scene = false;
 
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
-        RRTX_HIP(hipMalloc(dst, bytes));
-        RRTX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        if (int e = ensure_buffer(c, dst, bytes)) return e;
+        if (bytes) RRTX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return 0;
     };
     int rc;
@@ -159,9 +178,6 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if ((rc = up(&c->d_mat, hmat.data(), hmat.size() * sizeof(MaterialRec<F>)))) return rc;
     c->tail_ok = packed.tail_ok;
     // accelerated closest hit (the reference's -b switches its BVH off, main.cpp:67,90)
-    for (void *p : {(void *)c->d_grid_cell_start, (void *)c->d_grid_cell_prims, (void *)c->d_grid_always})
-        if (p) (void)hipFree(p);
-    c->d_grid_cell_start = c->d_grid_always = nullptr, c->d_grid_cell_prims = nullptr;
     c->accel = false, c->tail_grid = false;
     // (also without use_bvh: the paths a list-scan launch parks at its end - half a percent of its segments - are then
     // finished lane per ray through the grid instead of 8 lanes per ray on the list: 0.75 against 1.25 ms for an eighth of the
@@ -238,8 +254,8 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
         P.n_always = c->n_always, P.n_grid_cells = c->n_grid_cells, P.n_grid_prims = c->n_grid_prims;
         memcpy(&P.grid, c->grid_bytes, sizeof(GridRec<F>));
     }
-    P.plist = c->d_plist;
-    P.list_passes = c->d_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
+    P.plist = c->have_plist ? c->d_plist : nullptr;
+    P.list_passes = c->have_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
     P.verify_lists = (c->p.flags & RRTX_FLAG_VERIFY_LISTS) ? 1 : 0;
     P.diag = nullptr;
 #ifdef RRTX_DIAG
@@ -257,6 +273,7 @@ void free_scene_buffers(rrtx_ctx *c)
         if (*b) (void)hipFree(*b);
         *b = nullptr;
     }
+    c->caps.clear();
     c->have_scene = false;
     c->accel = c->tail_grid = false;
     c->tail_capacity = 0;
@@ -466,7 +483,10 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     if ((s->num_spheres && !s->spheres) || (s->num_moving_spheres && !s->moving_spheres) || (s->num_triangles && !s->triangles))
         return fail(RRTX_E_INVALID, "rrtx_set_scene: count without table");
     if ((int64_t)s->num_spheres + s->num_moving_spheres + s->num_triangles > (1 << 28)) return fail(RRTX_E_INVALID, "rrtx_set_scene: too many primitives");
-    if (c->stream) RRTX_HIP(hipStreamSynchronize(c->stream));
+    // (the tables of the previous scene are overwritten in place: nothing may still be rendering from them, on whatever stream
+    // the caller launched - rrtx_render_device takes any)
+    RRTX_HIP(hipSetDevice(c->device));
+    RRTX_HIP(hipDeviceSynchronize());
     int rc = c->p.fp64 ? upload_scene<double>(c, s) : upload_scene<float>(c, s);
     if (rc) return rc;
     // persistent grid: fill the chip once with the kernel variant this scene selects; never more
@@ -481,17 +501,14 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
     // camera-ray candidate lists (one pre-pass per scene: they depend on the camera and the spheres)
-    if (c->d_plist) {
-        (void)hipFree(c->d_plist);
-        c->d_plist = nullptr;
-    }
+    c->have_plist = false;
     // (a LIST pass tests every moving sphere and triangle per camera ray, with the few lanes that hold one: with a
     // mesh in the scene the walk resp. the scan pass, which has to go through them anyway, is the cheaper way)
     if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && c->n_tri + c->n_msph <= 64) {
         const size_t bytes = (size_t)c->local_rows * c->p.image_width * kPlistStride * sizeof(uint16_t);
-        uint16_t *pl = nullptr;
-        RRTX_HIP(hipMalloc((void **)&pl, bytes));
-        c->d_plist = pl; // owned by the context from here on: a failing launch below must not leak it
+        if (int e = ensure_buffer(c, (void **)&c->d_plist, bytes)) return e;
+        uint16_t *pl = c->d_plist;
+        c->have_plist = true;
         if (c->p.fp64) {
             KernelParams<double> P = make_params<double>(c, nullptr, c->accel);
             RRTX_HIP(launch_primary_lists<double>(P, pl, c->stream));
@@ -503,26 +520,16 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         RRTX_HIP(hipStreamSynchronize(c->stream));
     }
     // parked-item buffer: every resident wave can park at most kHandoffLanes items
-    if (c->d_tail_items) {
-        (void)hipFree(c->d_tail_items);
-        c->d_tail_items = nullptr;
-    }
-    if (c->d_tail_rad) {
-        (void)hipFree(c->d_tail_rad);
-        c->d_tail_rad = nullptr;
-    }
-    if (c->d_tail_units) {
-        (void)hipFree(c->d_tail_units);
-        c->d_tail_units = nullptr;
-    }
     c->tail_capacity = 0;
     if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
         const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
         c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
-        c->tail_capacity = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
-        RRTX_HIP(hipMalloc(&c->d_tail_items, c->tail_capacity * item));
-        RRTX_HIP(hipMalloc(&c->d_tail_rad, c->tail_capacity * kTailSplit * 3 * c->fsize));
-        RRTX_HIP(hipMalloc((void **)&c->d_tail_units, c->tail_capacity * kTailSplit * sizeof(uint32_t)));
+        const size_t items = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
+        // (tail_capacity stays 0 - no hand-off - unless all three buffers are there)
+        if (int e = ensure_buffer(c, &c->d_tail_items, items * item)) return e;
+        if (int e = ensure_buffer(c, &c->d_tail_rad, items * kTailSplit * 3 * c->fsize)) return e;
+        if (int e = ensure_buffer(c, (void **)&c->d_tail_units, items * kTailSplit * sizeof(uint32_t))) return e;
+        c->tail_capacity = items;
         int64_t tb = (int64_t)(c->tail_capacity + kWavesPerBlock - 1) / kWavesPerBlock; // one wave per item at most
         const int64_t cap = (int64_t)c->num_cus * 8;
         c->tail_blocks = (int)(tb < cap ? tb : cap);
