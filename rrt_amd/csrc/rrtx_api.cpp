@@ -274,7 +274,7 @@ void free_scene_buffers(rrtx_ctx *c)
         *b = nullptr;
     }
     c->caps.clear();
-    c->have_scene = false;
+    c->have_scene = c->have_plist = false;
     c->accel = c->tail_grid = false;
     c->tail_capacity = 0;
 }
