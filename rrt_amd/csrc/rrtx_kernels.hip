@@ -1170,12 +1170,41 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
 
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
 // number of devices).  Launched unless every pixel is a single task.
-template <typename F> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, FinalizeShape S)
+// kFinalizeGroup chunked pixels per block: their partial sums - [pixel][chunk][3], one contiguous slab - are staged through
+// LDS with coalesced loads, then one thread per (pixel, channel) adds its chunks in order (the ORDER is part of the image: no
+// tree reduction).  Read straight from HBM by those threads, 12 bytes here and 12 bytes a pixel further on, the same sums cost
+// 0.51 instead of 0.20 ms at 1200x800 spp 500.  STAGED = false: the plain form, for slabs that do not fit.
+constexpr int kFinalizeGroup = 16;
+constexpr size_t kFinalizeLdsBytes = 48 * 1024;
+template <typename F, bool STAGED> __global__ void __launch_bounds__(256) finalize_kernel(const F *__restrict__ partial, F *__restrict__ fb, FinalizeShape S)
 {
-    // one thread per (pixel, channel) value
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     const uint32_t n_values = S.n_pixels * 3u, n_chunked = S.taper_pixel * 3u;
+    uint32_t v_begin = 0; // values below this one were formed by the staged part
+    if (STAGED) {
+        F *const slab = (F *)dyn_lds;
+        const uint32_t per_pixel = (uint32_t)S.chunks_per_pixel * 3u;
+        const uint32_t n_groups = (S.taper_pixel + kFinalizeGroup - 1) / kFinalizeGroup;
+        for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+            const uint32_t q0 = g * kFinalizeGroup;
+            const uint32_t n_px = S.taper_pixel - q0 < (uint32_t)kFinalizeGroup ? S.taper_pixel - q0 : (uint32_t)kFinalizeGroup;
+            const F *src = partial + (size_t)q0 * per_pixel;
+            for (uint32_t i = threadIdx.x; i < n_px * per_pixel; i += blockDim.x) slab[i] = src[i];
+            __syncthreads();
+            if (threadIdx.x < n_px * 3u) {
+                const uint32_t q = threadIdx.x / 3u, ch = threadIdx.x - q * 3u;
+                const F *p = slab + q * per_pixel + ch;
+                F s = 0;
+                for (int c = 0; c < S.chunks_per_pixel; ++c) s = s + p[c * 3];
+                fb[(size_t)(q0 + q) * 3 + ch] = s;
+            }
+            __syncthreads();
+        }
+        v_begin = n_chunked;
+    }
+    // one thread per (pixel, channel) value
     const F *const samples = partial + (size_t)n_chunked * S.chunks_per_pixel;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
+    for (uint32_t v = v_begin + blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += gridDim.x * blockDim.x) {
         F s = 0;
         if (v < n_chunked) {
             const uint32_t q = v / 3u, ch = v - q * 3u;
@@ -1292,10 +1321,17 @@ template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filt
 }
 template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const FinalizeShape &S, hipStream_t stream)
 {
+    const size_t slab = (size_t)kFinalizeGroup * (size_t)S.chunks_per_pixel * 3 * sizeof(F);
+    if (S.taper_pixel > 0 && S.chunks_per_pixel > 1 && slab <= kFinalizeLdsBytes) {
+        uint32_t blocks = (S.taper_pixel + kFinalizeGroup - 1) / kFinalizeGroup;
+        if (blocks > 8192u) blocks = 8192u;
+        hipLaunchKernelGGL((finalize_kernel<F, true>), dim3(blocks), dim3(256), slab, stream, partial, fb, S);
+        return hipGetLastError();
+    }
     int blocks = (int)((S.n_pixels * 3u + 255u) / 256u);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(finalize_kernel<F>, dim3(blocks), dim3(256), 0, stream, partial, fb, S);
+    hipLaunchKernelGGL((finalize_kernel<F, false>), dim3(blocks), dim3(256), 0, stream, partial, fb, S);
     return hipGetLastError();
 }
 template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool filter, int lds_mode, int *blocks_per_cu)
