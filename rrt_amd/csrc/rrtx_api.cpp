@@ -192,8 +192,14 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
         // under an empirical inflation, unless the caller insists on the list scan's bits (RRTX_FLAG_EXACT_ACCEL): the
         // reference's own default, its BVH, has the same hazard band against its own list scan (bvh.h:167-175)
         bool approximate = false;
-        if (build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G,
-                          c->p.use_bvh && !(c->p.flags & RRTX_FLAG_EXACT_ACCEL), &approximate)) {
+        bool built = build_grid<F>(hhot, hcold, s->num_spheres, n_pad, hms, s->num_moving_spheres, htri, s->num_triangles, camrec, cell_start, cell_prims, always, G,
+                                   c->p.use_bvh && !(c->p.flags & RRTX_FLAG_EXACT_ACCEL), &approximate);
+        // (a handful of primitives: no grid, the list is scanned also under use_bvh - but the END of the launch still goes
+        // through a grid of nothing but an always-list: build_degenerate_grid)
+        bool degenerate = false;
+        if (!built && !(c->p.flags & (RRTX_FLAG_NO_TAIL_GRID | RRTX_FLAG_NO_TAIL_KERNEL | RRTX_FLAG_VERIFY_LISTS)))
+            built = degenerate = build_degenerate_grid<F>(s->num_spheres, n_pad, s->num_moving_spheres, s->num_triangles, cell_start, cell_prims, always, G);
+        if (built) {
             c->accel_exact = !approximate;
             if (cell_prims.empty()) cell_prims.push_back(0);
             if (always.empty()) always.push_back(0), c->n_always = 0;
@@ -204,7 +210,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             c->n_grid_cells = (int)cell_start.size() - 1;
             c->n_grid_prims = (int)cell_start.back();
             memcpy(c->grid_bytes, &G, sizeof G);
-            c->accel = c->p.use_bvh != 0;
+            c->accel = c->p.use_bvh != 0 && !degenerate;
             c->tail_grid = !c->accel;
         }
     }

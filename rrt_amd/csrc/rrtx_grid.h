@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <vector>
 
 #include "rrtx_device.h"
@@ -308,6 +309,31 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         return true;
     }
     return false;
+}
+
+// A grid without cells for scenes of a handful of primitives (build_grid() declines below 32 griddable ones): EVERYTHING
+// sits in the always-list, the box is a point no ray is asked to walk through.  It exists for the end of a list-scan launch:
+// the parked paths of such a scene are then finished lane per ray by the resume pass (4 exact tests per segment on test1.txt)
+// instead of by the tail kernel with its 8 lanes per ray (0.55 of the 1.55 ms of BASELINE configuration 2).  Exact by the same
+// argument as the always-list of any grid.  false: too many primitives for an always-list.
+template <typename F>
+inline bool build_degenerate_grid(int n_sph, int n_sph_pad, int n_msph, int n_tri, std::vector<uint32_t> &cell_start, std::vector<GridPrim> &cell_prims, std::vector<uint32_t> &always, GridRec<F> &G)
+{
+    if ((int64_t)n_sph + n_msph + n_tri > 48) return false;
+    always.clear();
+    for (int i = 0; i < n_sph; ++i) always.push_back((uint32_t)i);
+    for (int i = 0; i < n_msph; ++i) always.push_back((uint32_t)(n_sph_pad + i));
+    for (int i = 0; i < n_tri; ++i) always.push_back((uint32_t)(n_sph_pad + n_msph + i));
+    cell_start.assign(2, 0u);
+    cell_prims.assign(1, (GridPrim)0);
+    G = GridRec<F>();
+    for (int k = 0; k < 3; ++k) G.gmin[k] = G.gmax[k] = G.center[k] = (F)0, G.cell[k] = G.inv_cell[k] = (F)1, G.dims[k] = 1;
+    G.far2 = std::numeric_limits<F>::infinity(); // no ray is "far": there is nothing in the cells it could miss
+    G.slack = G.slack1 = G.half_diag = (F)0;
+    G.max_steps = 4 + (int)always.size();
+    G.dir2_max = (F)(sizeof(F) == 4 ? 1e15 : 1e120);
+    G.walk_slice = 4;
+    return true;
 }
 
 } // namespace rrtx
