@@ -505,12 +505,21 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             bool still_walking = false;
             if (list_pass) {
                 // exact tests in primitive order: listed spheres, then every moving sphere and triangle
+                // (the pixel's 32-byte list comes in with two 16-byte loads and is parked in this lane's candidate slots in LDS -
+                // free during a LIST pass -, the entries are picked from there instead of one by one from L2, each a dependent load
+                // in front of the record's; use_bvh 41.3 -> 41.0 ms, list scan unchanged: the LIST passes - 22.7 % of the accelerated
+                // kernel's cycles, 9.2 % of the list scan's, a quarter of the lanes at work - are bound by issue, not by these loads)
+                static_assert(kPlistStride == 16 && kCap >= 8, "a pixel's list is 8 dwords");
                 const auto &C = *cold_params<F>();
-                const uint16_t *pl = C.plist + (size_t)task_pixel<F>(C, task) * kPlistStride + 1;
+                typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+                const U4 *pl4 = (const U4 *)(C.plist + (size_t)task_pixel<F>(C, task) * kPlistStride);
+                const U4 lo4 = pl4[0], hi4 = pl4[1];
+                my_cand[0 * 64] = lo4.x, my_cand[1 * 64] = lo4.y, my_cand[2 * 64] = lo4.z, my_cand[3 * 64] = lo4.w;
+                my_cand[4 * 64] = hi4.x, my_cand[5 * 64] = hi4.y, my_cand[6 * 64] = hi4.z, my_cand[7 * 64] = hi4.w;
                 n_candidates += plist_count;
-                for (uint32_t k = 0; k < plist_count; ++k) {
-                    const int idx = (int)pl[k];
-                    const SphereHot<F> gq = P.sph_hot[idx];
+                for (uint32_t k = 1; k <= plist_count; ++k) { // halfword 0 is the count, entries follow
+                    const int idx = (int)((my_cand[(k >> 1) * 64] >> ((k & 1u) * 16u)) & 0xFFFFu);
+                    const SphereHot<F> gq = ACCEL == 2 ? hot_lds[idx] : P.sph_hot[idx];
                     refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, idx, best);
                 }
                 for (int q = 0; q < n_msph; ++q) {
@@ -550,6 +559,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             }
             else {
             bool need_scan = true;
+            if (ACCEL != 0) RRTX_SEC(7); // (developer builds: the grid walk, apart from the LIST passes of section 2)
             if (ACCEL != 0) {
                 const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
                 const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.walk_slice; // (the macro: experiments)

@@ -7,7 +7,7 @@ import rrt_amd
 from rrt_amd._lib import lib
 from _oracle import scene_path
 W, H, spp = 1200, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 100
-NAMES = ["hand-out / polling / hand-off", "camera rays", "camera-ray lists | grid walk", "scan phase 1 (filter)", "scan phase 2 (exact refinement)", "shading", "sample / task bookkeeping", "exit"]
+NAMES = ["hand-out / polling / hand-off", "camera rays", "camera-ray lists (LIST passes)", "scan phase 1 (filter)", "scan phase 2 (exact refinement)", "shading", "sample / task bookkeeping", "grid walk (use_bvh)"]
 for fp64 in (False, True):
     s = rrt_amd.Scene(scene_path("final"), W, H, fp64=fp64)
     for bvh in (False, True):
