@@ -121,3 +121,11 @@ def test_reference_side_binding_is_compiled_against_the_reference_headers():
         if rrt_amd.device_count() == 0:
             r = subprocess.run([path, "-i", os.path.join(ROOT, "scenes", "test1.txt"), "-w", "16", "-h", "16", "-s", "1"], capture_output=True)
             assert r.returncode == 99 and b"HIP error" in r.stderr and r.stdout == b""
+
+
+def test_integration_md_shows_the_file_that_is_compiled():
+    # the binding INTEGRATION.md section 1 tells a maintainer to add IS oracle/ref_dropin.cpp (compiled and tested), not a sketch
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "oracle", "ref_dropin.cpp")).read()
+    body = src[src.index('#include "rrt.h"'):]
+    assert body in doc
