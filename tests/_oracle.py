@@ -255,3 +255,56 @@ def mesh_scene(path, nu=16, nv=32, camera="camera 6 2.5 7 0 0.8 0 0 1 0 35 0.05 
     lines += ["obj_end", "obj 0 r t 0 1.0 0", "obj 0 m s 0.6 0.6 0.6 t 2.2 0.6 1.5", "obj 0 g s 0.7 0.5 0.7 r 40 0 0 1 t -2.0 0.7 1.0"]
     open(path, "w").write("\n".join(lines) + "\n")
     return str(path), 3 * len(tris)
+
+
+def random_scene(rng, path):
+    """A valid scene file exercising the whole grammar of scene.h:224-428 with random content: number
+    formats std::stod accepts, optional shutter times, duplicate and unknown material names, ignored lines, objs with
+    several instances and transform chains in random order."""
+    def num(lo, hi):
+        v = float(rng.uniform(lo, hi))
+        return rng.choice(["%r" % v, "%.3f" % v, "%.6e" % v, "%+.4f" % v, "%d" % int(round(v)) if abs(v) >= 1 else "%.2f" % v])
+
+    lines = ["# random scene", "", "  sphere 0 0 0 1 indented_lines_are_ignored"]
+    cam = "camera %s %s %s  %s %s %s  0 1 0  %s %s %s" % (num(3, 14), num(1, 5), num(2, 9), num(-1, 1), num(-0.5, 1), num(-1, 1), num(15, 70), num(0, 0.3), num(4, 14))
+    if rng.random() < 0.5:
+        cam += " %s %s" % (num(0, 0.2), num(0.3, 1.0))
+    lines.append(cam)
+    names = []
+    for k in range(int(rng.integers(2, 9))):
+        name = "m%d" % (k if rng.random() > 0.15 or not names else 0)  # now and then a duplicate name
+        kind = rng.choice(["lambertian", "metal", "dielectric"])
+        if kind == "lambertian":
+            lines.append("material %s lambertian %s %s %s" % (name, num(0, 1), num(0, 1), num(0, 1)))
+        elif kind == "metal":
+            lines.append("material %s metal %s %s %s %s" % (name, num(0, 1), num(0, 1), num(0, 1), num(0, 1.5)))  # fuzz > 1 is clamped later
+        else:
+            lines.append("material %s dielectric %s" % (name, num(1.1, 2.4)))
+        names.append(name)
+        if rng.random() < 0.3:
+            lines.append("#material not_a_material lambertian 1 1 1")
+    pick = lambda: rng.choice(names) if rng.random() > 0.1 else "no_such_material"  # (maps to index 0, scene.h:310)
+    lines.append("sphere 0 -1000 0 1000 %s" % names[0])
+    for _ in range(int(rng.integers(1, 12))):
+        lines.append("sphere %s %s %s %s %s" % (num(-6, 6), num(0.1, 1.5), num(-6, 6), num(0.05, 1.2), pick()))
+    for _ in range(int(rng.integers(0, 4))):
+        lines.append("msphere %s %s %s  %s %s %s  %s %s  %s %s" % (num(-4, 4), num(0.2, 1), num(-4, 4), num(-4, 4), num(0.2, 1.5), num(-4, 4), num(0, 0.3), num(0.5, 1), num(0.1, 0.5), pick()))
+    n_obj = int(rng.integers(0, 3))
+    for _ in range(n_obj):
+        nv, nt = int(rng.integers(3, 9)), int(rng.integers(1, 7))
+        lines.append("obj_beg %d %d" % (nv, nt))
+        lines += ["obj_vtx %s %s %s" % (num(-1, 1), num(-1, 1), num(-1, 1)) for _ in range(nv)]
+        lines += ["obj_tri %d %d %d" % tuple(int(x) for x in rng.choice(nv, 3, replace=False)) for _ in range(nt)]
+        lines.append("obj_end")
+    for _ in range(int(rng.integers(0, 4)) if n_obj else 0):
+        inst = "obj %d %s" % (int(rng.integers(0, n_obj)), pick())
+        for _ in range(int(rng.integers(0, 4))):
+            kind = rng.choice(["t", "s", "r"])
+            if kind == "r":
+                ax = rng.normal(size=3)
+                ax /= np.linalg.norm(ax)
+                inst += " r %s %r %r %r" % (num(-180, 180), float(ax[0]), float(ax[1]), float(ax[2]))
+            else:
+                inst += " %s %s %s %s" % (kind, num(-2, 2) if kind == "t" else num(0.3, 2), num(-2, 2) if kind == "t" else num(0.3, 2), num(-2, 2) if kind == "t" else num(0.3, 2))
+        lines.append(inst)
+    open(path, "w").write("\n".join(str(x) for x in lines) + "\n")

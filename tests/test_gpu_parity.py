@@ -572,3 +572,27 @@ def test_accelerated_closest_hit_on_hostile_geometry(gpu, tmp_path, fp64):
         assert st["list_mismatches"] == 0, cam
         assert np.array_equal(fb, want), cam
         assert np.array_equal(_render(gpu, str(path), w, h, spp, fp64=fp64, use_bvh=True)[0], want), cam
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_random_scenes_in_both_modes(gpu, tmp_path, fp64):
+    """Scene files with random content over the whole grammar (tests/_oracle.py: random_scene - all three materials, moving
+    spheres with and without shutter, objs instanced under random transform chains, unknown material names ...): every pixel
+    equal to the oracle's in the list scan, and in the accelerated mode wherever the grid in use is the proven one (fp32 scenes
+    whose triangles were gridded under the approximate rule: at most one pixel in 10^4)."""
+    from _oracle import random_scene
+
+    rng = np.random.default_rng(77)
+    for k in range(12):
+        f = str(tmp_path / ("rand%d.txt" % k))
+        random_scene(rng, f)
+        w, h, spp = int(rng.integers(24, 72)), int(rng.integers(16, 48)), int(rng.integers(1, 6))
+        want, so = Oracle(f, w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+        fb, st = _render(gpu, f, w, h, spp, fp64=fp64)
+        assert np.array_equal(fb, want), (k, "list scan")
+        assert st["segments"] == so["segments"]
+        fa, sa = _render(gpu, f, w, h, spp, fp64=fp64, use_bvh=True)
+        if sa["accel_exact"]:
+            assert np.array_equal(fa, want), (k, "use_bvh")
+        else:
+            assert ((fa != want).any(axis=2)).mean() <= 1e-4, k

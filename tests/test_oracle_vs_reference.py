@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from _oracle import GOLDEN, Oracle, Reference, have_reference, scene_path
+from _oracle import GOLDEN, Oracle, Reference, have_reference, random_scene as _random_scene, scene_path
 
 pytestmark = pytest.mark.skipif(not have_reference(), reason="oracle/_ref not built (needs /root/reference)")
 
@@ -94,3 +94,45 @@ def test_reference_bvh_and_list_scan_agree(name):
     b = r.render(3, 50, 1984, bvh=True)
     same = np.all(a == b, axis=2).mean()
     assert same > 0.999, same
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_parsers_agree_on_random_scenes(tmp_path, fp64):
+    """Differential fuzz of the three parsers on 25 random valid scene files: the reference's scene.h (compiled), the oracle's
+    restatement and the product's host_scene.cpp - tables equal value for value, the product's equal to the reference's raw
+    POD bytes field by field - and the oracle renders what the reference renders on them."""
+    import rrt_amd
+    import rrt_amd.render as rr
+
+    dt = rr._table_dtypes(fp64)
+    rng = np.random.default_rng(20261004)
+    for k in range(25):
+        path = str(tmp_path / ("rand%d.txt" % k))
+        _random_scene(rng, path)
+        w, h = int(rng.integers(8, 64)), int(rng.integers(8, 48))
+        ref, o = Reference(path, w, h, fp64), Oracle(path, w, h, fp64)
+        tr, to = ref.tables(), o.tables()
+        assert to.counts == tr.counts, (k, to.counts, tr.counts)
+        for key in ("cam", "materials", "spheres", "msph", "tris"):
+            assert np.array_equal(getattr(to, key), getattr(tr, key)), (k, key)
+        cam, mats, sph, msph, tris = ref.raw()
+        t = rrt_amd.Scene(path, w, h, fp64=fp64).tables()
+        rcam = np.frombuffer(cam.tobytes(), dtype=dt["camera"])[0]
+        for f in dt["camera"].names:
+            assert np.array_equal(rcam[f], t["camera"][f]), (k, f)
+        for key, raw, dkey in (("spheres", sph, "sphere"), ("moving_spheres", msph, "msphere"), ("triangles", tris, "triangle")):
+            r = np.frombuffer(raw.tobytes(), dtype=dt[dkey])
+            assert len(r) == len(t[key]), (k, key)
+            for f in dt[dkey].names:
+                assert np.array_equal(r[f], t[key][f]), (k, key, f)
+        rm = np.frombuffer(mats.tobytes(), dtype=dt["material"])
+        assert np.array_equal(rm["type"], t["materials"]["type"]), k
+        for i, ty in enumerate(rm["type"]):
+            if ty in (0, 1):
+                assert np.array_equal(rm["albedo"][i], t["materials"]["albedo"][i]), (k, i)
+            if ty == 1:
+                assert rm["fuzz"][i] == t["materials"]["fuzz"][i], (k, i)
+            if ty == 2:
+                assert rm["ref_idx"][i] == t["materials"]["ref_idx"][i], (k, i)
+        if k < 8:
+            assert np.array_equal(o.render(2, 50, 7 + k, order=0)[0], ref.render(2, 50, 7 + k)), k
