@@ -131,3 +131,33 @@ def test_multi_gpu_front_end_writes_the_same_png(gpu, tmp_path):
     p = subprocess.run([sys.executable, "-m", "rrt_amd.dist", "-i", scene_path("final"), "-o", out, "-w", str(w), "-h", str(h), "-s", str(spp)], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert np.array_equal(np.asarray(Image.open(out)), want)
+
+
+def test_bench_line_of_a_two_rank_run(gpu):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed with two ranks over
+    gloo on this box's GPU (RRTX_BENCH_BACKEND=gloo: the ranks share the device, the gather is staged through the host - the
+    plumbing is what is checked, the numbers mean nothing): ONE JSON line on stdout with the contract's fields, the 8-GPU
+    workload of BASELINE.json (configuration 5) as the default for N > 1, kernel-only time beside the step time."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from _oracle import ROOT
+
+    env = dict(os.environ, RRTX_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "24"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]  # one line, nothing else on stdout
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["warmup"] == 0 and j["unit"] == "Msamples/s" and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert j["scaling"] == "strong" and "3840x2160" in j["config"]["workload"] and "x2" in j["config"]["parallelism"]
+    assert abs(j["value"] - 3840 * 2160 * 24 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * j["value"]
+    assert j["kernel_only_ms_per_step"] > 0 and j["gather_ms_per_step"] >= 0
+    assert j["roofline"]["bound"] == "valu_issue" and 0 < j["roofline"]["frac"] <= 1 and "logical_hbm" in j["roofline"]
+    assert "cpu_baseline" not in j  # rank 0 at N = 1 only
