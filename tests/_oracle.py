@@ -308,3 +308,18 @@ def random_scene(rng, path):
                 inst += " %s %s %s %s" % (kind, num(-2, 2) if kind == "t" else num(0.3, 2), num(-2, 2) if kind == "t" else num(0.3, 2), num(-2, 2) if kind == "t" else num(0.3, 2))
         lines.append(inst)
     open(path, "w").write("\n".join(str(x) for x in lines) + "\n")
+
+
+def degenerate_scene(path):
+    """What a scene file can legally contain and a renderer trips over: a sphere of radius 0, the hollow-glass idiom of a
+    NEGATIVE radius (sphere.h:38,53: hit by r*r, normal (p - c) / r flipped), two identical spheres (every hit a tie), a
+    triangle of zero area (collinear vertices: its unit normal is 0/0 - never hit, |a| < 1e-7, but packed and gridded), a
+    triangle with a repeated vertex, a moving sphere that does not move and one whose own time interval is empty, in a camera
+    with a shutter."""
+    lines = ["camera 0 1.5 7 0 0.8 0 0 1 0 35 0.08 7 0.0 1.0", "material a lambertian 0.7 0.4 0.3", "material g dielectric 1.5", "material m metal 0.8 0.8 0.9 0.0",
+             "sphere 0 -100 0 100 a", "sphere 0 1 0 1.0 g", "sphere 0 1 0 -0.9 g", "sphere -2.2 0.7 0.5 0.7 m", "sphere -2.2 0.7 0.5 0.7 a", "sphere 2 0.5 1 0 a",
+             "msphere 2.2 0.6 0.3  2.2 0.6 0.3  0 1  0.6 m", "msphere -0.8 0.3 2.5  -0.2 0.5 2.5  0.5 0.5  0.3 a",
+             "obj_beg 6 3", "obj_vtx 0 0 0", "obj_vtx 1 0 0", "obj_vtx 2 0 0", "obj_vtx 0 1 0", "obj_vtx 1 1 0.2", "obj_vtx 0.3 0.2 0.9",
+             "obj_tri 0 1 2", "obj_tri 0 0 3", "obj_tri 3 4 5", "obj_end", "obj 0 a t 0.5 0.3 3", "obj 0 m s 0.8 0.8 0.8 r 30 0 1 0 t -2 0.2 3"]
+    open(str(path), "w").write("\n".join(lines) + "\n")
+    return str(path)

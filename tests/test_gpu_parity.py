@@ -596,3 +596,21 @@ def test_random_scenes_in_both_modes(gpu, tmp_path, fp64):
             assert np.array_equal(fa, want), (k, "use_bvh")
         else:
             assert ((fa != want).any(axis=2)).mean() <= 1e-4, k
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_degenerate_primitives(gpu, tmp_path, fp64):
+    """Degenerate primitives (tests/_oracle.py: degenerate_scene - radius 0, negative radius, coincident spheres, zero-area
+    triangles, moving spheres that do not move or whose time interval is empty): every pixel equal to the oracle's in both
+    modes (fp32 + use_bvh: the always-list, 14 primitives).  The oracle itself is held to the compiled reference on this scene
+    by tests/test_oracle_vs_reference.py."""
+    from _oracle import degenerate_scene
+
+    f = degenerate_scene(tmp_path / "degenerate.txt")
+    w, h, spp = 96, 64, 5
+    want, so = Oracle(str(f), w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+    assert np.isfinite(want).all()
+    for use_bvh in (False, True):
+        fb, st = _render(gpu, str(f), w, h, spp, fp64=fp64, use_bvh=use_bvh)
+        assert np.array_equal(fb, want), use_bvh
+        assert st["segments"] == so["segments"]

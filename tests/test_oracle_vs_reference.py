@@ -136,3 +136,17 @@ def test_parsers_agree_on_random_scenes(tmp_path, fp64):
                 assert rm["ref_idx"][i] == t["materials"]["ref_idx"][i], (k, i)
         if k < 8:
             assert np.array_equal(o.render(2, 50, 7 + k, order=0)[0], ref.render(2, 50, 7 + k)), k
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_degenerate_primitives_like_the_reference(tmp_path, fp64):
+    # radius 0, negative radius, coincident spheres, zero-area triangles, moving spheres that stand still (tests/_oracle.py)
+    from _oracle import degenerate_scene
+
+    f = degenerate_scene(tmp_path / "degenerate.txt")
+    o, r = Oracle(f, 60, 40, fp64), Reference(f, 60, 40, fp64)
+    to, tr = o.tables(), r.tables()
+    assert to.counts == tr.counts
+    for key in ("cam", "materials", "spheres", "msph", "tris"):
+        assert np.array_equal(getattr(to, key), getattr(tr, key), equal_nan=True), key
+    assert np.array_equal(o.render(4, 50, 1984, order=0)[0], r.render(4, 50, 1984), equal_nan=True)
