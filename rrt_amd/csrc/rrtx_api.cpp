@@ -541,6 +541,9 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         c->tail_blocks = (int)(tb < cap ? tb : cap);
         if (c->tail_blocks < 1) c->tail_blocks = 1;
         c->resume_blocks = c->grid_blocks; // (persistent waves pulling units: blocks beyond what is resident just find the queue empty)
+#ifdef RRTX_EXPERIMENTS
+        c->resume_blocks = (int)grid_knob("RRTX_RESUME_BLOCKS", (double)c->resume_blocks);
+#endif
     }
     return RRTX_OK;
 }
@@ -567,7 +570,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     }
     if (c->total_tasks == 0) return RRTX_OK;
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 256, st)); // task cursor, parked-item count, tail cursor, unit count; queue-over flag
-#ifdef RRTX_SECTION_DIAG
+#if defined(RRTX_SECTION_DIAG) || defined(RRTX_RESUME_DIAG)
     RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 256, st));
 #else
     if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 32, st));
@@ -615,6 +618,14 @@ extern "C" int rrtx_diag_read(rrtx_ctx *c, void *dst)
 }
 #endif
 
+#ifdef RRTX_RESUME_DIAG
+extern "C" int rrtx_resume_diag(rrtx_ctx *c, unsigned long long out[8]) // developer builds: the resume pass's longest wave (iterations, cycles); iterations of all waves, waves with work, segments
+{
+    RRTX_HIP(hipDeviceSynchronize());
+    RRTX_HIP(hipMemcpy(out, c->d_counters + 24, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 #ifdef RRTX_SECTION_DIAG
 extern "C" int rrtx_section_diag(rrtx_ctx *c, unsigned long long out[8]) // developer builds: a wave's clock cycles per section of the render loop, summed over the waves
 {

@@ -266,6 +266,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     bool single = false;    // RESUME: the result is the sample itself (units k >= 1), not a running sum
     const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
+#ifdef RRTX_RESUME_DIAG
+    const unsigned long long resume_t0 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t plist_count = 0xFFFFu; // header of the current pixel's camera-ray list
     // ACCEL: a grid walk in progress (see accel_closest_hit)
     bool in_walk = false;
@@ -770,9 +773,24 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
         atomicAdd(&P.counters[3], (unsigned long long)n_scanned);
     }
+#ifdef RRTX_RESUME_DIAG // developer builds (tools/resume_diag.py): the longest wave of a resume pass - iterations, clock cycles -, and the pass's totals
+    if (RESUME) {
+        if (lane == 0) {
+            atomicMax(&P.counters[24], (unsigned long long)loop_count);
+            atomicMax(&P.counters[25], (unsigned long long)(__builtin_amdgcn_s_memtime() - resume_t0));
+            atomicAdd(&P.counters[26], (unsigned long long)loop_count);
+            atomicAdd(&P.counters[27], loop_count > 1 ? 1ull : 0ull);
+        }
+        if (n_segments) atomicAdd(&P.counters[28], (unsigned long long)n_segments);
+    }
+#endif
 #ifdef RRTX_SECTION_DIAG
     RRTX_SEC(7);
+#ifdef RRTX_SECTION_RESUME // (the resume pass's sections instead of the render pass's: tools/resume_sections.py)
+    if (lane == 0 && RESUME)
+#else
     if (lane == 0 && !RESUME)
+#endif
         for (int k = 0; k < 8; ++k) atomicAdd(&P.counters[16 + k], sec_cycles[k]);
 #endif
 #undef RRTX_SEC
