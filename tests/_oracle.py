@@ -310,6 +310,70 @@ def random_scene(rng, path):
     open(path, "w").write("\n".join(str(x) for x in lines) + "\n")
 
 
+def crowded_scene(rng, path):
+    """Random scenes with enough primitives for the acceleration grid (40 - 600): spheres over four orders of magnitude of
+    size - clusters of tiny ones, a few that dwarf a cell, some far from everything -, moving spheres, and one or two small
+    meshes instanced several times under random transforms; a camera anywhere, sometimes inside the crowd, sometimes far away."""
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    lines = []
+    far_cam = rng.random() < 0.2
+    span = u(2, 12)  # the crowd lives in [-span, span]^2 x [0, span / 2]
+    cd = u(40, 400) if far_cam else u(0.5, 2.5) * span
+    ang, el = u(0, 2 * np.pi), u(0.05, 1.2)
+    cam = (float(cd * np.cos(ang) * np.cos(el)), float(cd * np.sin(el) + 0.2), float(cd * np.sin(ang) * np.cos(el)))
+    lines.append("camera %r %r %r  %r %r %r  0 1 0  %r %r %r%s" % (cam[0], cam[1], cam[2], u(-1, 1), u(0, 1), u(-1, 1), u(3, 12) if far_cam else u(20, 75), u(0, 0.2), max(0.5, cd * u(0.6, 1.2)),
+                                                               " 0.0 1.0" if rng.random() < 0.5 else ""))
+    lines += ["material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 %r" % u(0, 0.6), "material g dielectric 1.5", "material r lambertian 0.8 0.2 0.2", "material k metal 0.9 0.7 0.3 0.0"]
+    mats = "amgrk"
+    pick = lambda: mats[int(rng.integers(len(mats)))]
+    if rng.random() < 0.85:
+        lines.append("sphere 0 -1000 0 1000 a")
+    n = int(rng.choice([40, 60, 120, 300, 600]))
+    base = 10 ** u(-1.6, -0.3) * span / 4  # typical radius
+    for k in range(n):
+        kind = rng.random()
+        r = base * 10 ** u(-0.3, 0.3)
+        if kind < 0.03:
+            r = base * 10 ** u(0.8, 1.6)  # dwarfs a cell
+        elif kind < 0.08:
+            r = base * 10 ** u(-2.5, -1.2)  # tiny
+        x, z = u(-span, span), u(-span, span)
+        y = r if rng.random() < 0.6 else u(0, span / 2)
+        if kind > 0.97:
+            x, z = x * 8, z * 8  # far from everything
+        if rng.random() < 0.06:
+            lines.append("msphere %r %r %r  %r %r %r  0.0 1.0  %r %s" % (x, y, z, x + u(-1, 1) * r * 3, y + u(0, 1) * r * 3, z + u(-1, 1) * r * 3, r, pick()))
+        else:
+            lines.append("sphere %r %r %r %r %s" % (x, y, z, r if rng.random() > 0.02 else -r, pick()))
+    if rng.random() < 0.3:  # a cluster of coincident / nested spheres
+        cx, cz, cr = u(-span, span), u(-span, span), base
+        lines += ["sphere %r %r %r %r g" % (cx, cr, cz, cr), "sphere %r %r %r %r g" % (cx, cr, cz, -0.9 * cr), "sphere %r %r %r %r m" % (cx, cr, cz, cr), "sphere %r %r %r %r r" % (cx, cr, cz, 0.5 * cr)]
+    n_obj = int(rng.integers(0, 3))
+    for _ in range(n_obj):
+        nu, nv = int(rng.integers(2, 7)), int(rng.integers(3, 12))
+        verts = [(np.sin(np.pi * i / nu) * np.cos(2 * np.pi * j / nv), np.cos(np.pi * i / nu), np.sin(np.pi * i / nu) * np.sin(2 * np.pi * j / nv)) for i in range(nu + 1) for j in range(nv)]
+        tris = []
+        for i in range(nu):
+            for j in range(nv):
+                a, b, c, d = i * nv + j, i * nv + (j + 1) % nv, (i + 1) * nv + j, (i + 1) * nv + (j + 1) % nv
+                if i > 0:
+                    tris.append((a, c, b))
+                if i < nu - 1:
+                    tris.append((b, c, d))
+        lines.append("obj_beg %d %d" % (len(verts), len(tris)))
+        lines += ["obj_vtx %r %r %r" % tuple(float(x) for x in v) for v in verts]
+        lines += ["obj_tri %d %d %d" % t for t in tris]
+        lines.append("obj_end")
+    for _ in range(int(rng.integers(1, 6)) if n_obj else 0):
+        sc = base * 10 ** u(0.2, 1.2)
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        lines.append("obj %d %s s %r %r %r r %r %r %r %r t %r %r %r" % (int(rng.integers(n_obj)), pick(), sc * u(0.5, 1.5), sc * u(0.5, 1.5), sc * u(0.5, 1.5), u(-180, 180), float(ax[0]), float(ax[1]), float(ax[2]),
+                                                                      u(-span, span), sc + u(0, span / 3), u(-span, span)))
+    open(str(path), "w").write("\n".join(lines) + "\n")
+    return str(path)
+
+
 def degenerate_scene(path):
     """What a scene file can legally contain and a renderer trips over: a sphere of radius 0, the hollow-glass idiom of a
     NEGATIVE radius (sphere.h:38,53: hit by r*r, normal (p - c) / r flipped), two identical spheres (every hit a tie), a
