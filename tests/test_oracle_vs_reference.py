@@ -150,3 +150,24 @@ def test_degenerate_primitives_like_the_reference(tmp_path, fp64):
     for key in ("cam", "materials", "spheres", "msph", "tris"):
         assert np.array_equal(getattr(to, key), getattr(tr, key), equal_nan=True), key
     assert np.array_equal(o.render(4, 50, 1984, order=0)[0], r.render(4, 50, 1984), equal_nan=True)
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_crowded_scenes_like_the_reference(tmp_path, fp64):
+    """The scenes the GPU fuzz campaign draws half of its cases from (tests/_oracle.py: crowded_scene - 40 to 600 primitives
+    over four orders of magnitude of size, nested and negative-radius spheres, instanced meshes, cameras inside the crowd
+    and hundreds of units away): the oracle renders what the compiled reference renders on them, bit for bit, so that a GPU
+    frame equal to the oracle's there is equal to the reference's."""
+    from _oracle import crowded_scene
+
+    rng = np.random.default_rng(606)
+    for k in range(10):
+        f = crowded_scene(rng, tmp_path / ("crowd%d.txt" % k))
+        w, h = int(rng.integers(16, 56)), int(rng.integers(12, 40))
+        o, r = Oracle(f, w, h, fp64), Reference(f, w, h, fp64)
+        to, tr = o.tables(), r.tables()
+        assert to.counts == tr.counts, k
+        for key in ("cam", "materials", "spheres", "msph", "tris"):
+            assert np.array_equal(getattr(to, key), getattr(tr, key)), (k, key)
+        want = r.render(2, 50, 1984 + k)
+        assert np.array_equal(o.render(2, 50, 1984 + k, order=0)[0], want, equal_nan=True), k
