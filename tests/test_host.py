@@ -283,3 +283,66 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     subprocess.run(["g++"] + san + [os.path.join(ROOT, "tests", "path_host_check.cpp"), "-o", str(exe2)], check=True)
     r = subprocess.run([str(exe2), "60000"], capture_output=True, text=True)
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout + r.stderr
+
+
+def test_cli_batch_logic_under_thread_sanitizer(tmp_path):
+    """The CLI's host logic for batches (rrt_main.cpp: scenes dealt to workers, the next scene parsed ahead by a helper
+    thread, two writer tasks per worker over three frame buffers, PPMs on stdout in command-line order) under
+    ThreadSanitizer, with the device half of the C-ABI replaced by a stand-in that paints a pattern of the scene's counts
+    (tests/sanitize/fake_device.cpp - nothing is rendered here): no race reported, every image in its own file and equal
+    to the one a process of its own writes, stdout in order."""
+    csrc = os.path.join(ROOT, "rrt_amd", "csrc")
+    exe = str(tmp_path / "rrt_tsan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe, os.path.join(csrc, "rrt_main.cpp"), os.path.join(csrc, "host_scene.cpp"), os.path.join(csrc, "host_image.cpp"),
+                    os.path.join(ROOT, "tests", "sanitize", "fake_device.cpp"), "-lz", "-lpthread"], check=True)
+    xform = os.path.join(GOLDEN, "scenes", "xform.txt")
+    names = [scene_path("final"), scene_path("test1"), scene_path("test2"), scene_path("test3"), xform, scene_path("final"), scene_path("test2"), scene_path("test1"), xform]
+    size = ["-w", "96", "-h", "64", "-s", "3"]
+
+    def run(args, **kw):
+        r = subprocess.run([exe] + args, capture_output=True, timeout=600, **kw)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert b"ThreadSanitizer" not in r.stderr, r.stderr.decode()[-6000:]
+        return r
+
+    single = {}
+    for s in set(names):
+        o = str(tmp_path / "single.png")
+        run(size + ["-i", s, "-o", o])
+        single[s] = open(o, "rb").read()
+    assert len(set(single.values())) == len(single)  # (the stand-in tells the scenes apart)
+    for shape in (["-G", "3", "-E"], ["-G", "2"], []):
+        outs = [str(tmp_path / ("b%d.png" % i)) for i in range(len(names))]
+        args = size + shape
+        for s, o in zip(names, outs):
+            args += ["-i", s, "-o", o]
+        r = run(args)
+        assert r.stderr.count(b"took ") == len(names) and r.stdout == b""
+        for s, o in zip(names, outs):
+            assert open(o, "rb").read() == single[s], (shape, s)
+            os.remove(o)
+    # PPMs: stdout keeps the order of the command line
+    small = ["-w", "40", "-h", "30", "-s", "2"]
+    want = b"".join(run(small + ["-i", s]).stdout for s in names[:6])
+    for shape in (["-G", "2", "-E"], ["-G", "3", "-E"], []):
+        args = small + shape
+        for s in names[:6]:
+            args += ["-i", s]
+        assert run(args).stdout == want, shape
+    # one frame over a group; a scene that does not parse ends the batch with the reference's exit code
+    run(small + ["-G", "4", "-E", "-i", names[0], "-o", str(tmp_path / "g.png")])
+    bad = tmp_path / "bad.txt"
+    bad.write_text("camera 0 0 1 0 0 0 0 1 0 40 0 1\nmaterial a nosuchmaterial 1 1 1\nsphere 0 0 0 1 a\n")
+    # ... and the same sources under AddressSanitizer + UBSan: a dealt-out batch and a batch on one device
+    exe_a = str(tmp_path / "rrt_asan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe_a, os.path.join(csrc, "rrt_main.cpp"), os.path.join(csrc, "host_scene.cpp"),
+                    os.path.join(csrc, "host_image.cpp"), os.path.join(ROOT, "tests", "sanitize", "fake_device.cpp"), "-lz", "-lpthread"], check=True)
+    for shape in (["-G", "3", "-E"], []):
+        args = size + shape
+        for i, s in enumerate(names):
+            args += ["-i", s, "-o", str(tmp_path / ("a%d.png" % i))]
+        ra = subprocess.run([exe_a] + args, capture_output=True, timeout=600)
+        assert ra.returncode == 0 and b"Sanitizer" not in ra.stderr and b"runtime error" not in ra.stderr, ra.stderr.decode()[-4000:]
+        assert all(open(str(tmp_path / ("a%d.png" % i)), "rb").read() == single[s] for i, s in enumerate(names))
+    r = subprocess.run([exe] + small + ["-G", "2", "-i", names[1], "-o", str(tmp_path / "x.png"), "-i", str(bad), "-o", str(tmp_path / "y.png"), "-i", names[0], "-o", str(tmp_path / "z.png")], capture_output=True, timeout=600)
+    assert r.returncode == 3 and b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
