@@ -69,11 +69,47 @@ inline double grid_knob(const char *name, double dflt)
 // always-list.  In fp64 rho ~ 2e-8 |d| |e1| |e2|: meshes are gridded.  In fp32 rho ~ 10 |d| |e1| |e2|: the
 // bound admits nothing of practical size, and a mesh scene keeps the list scan.
 // ---------------------------------------------------------------------------------------------
+#ifndef RRTX_GRID_TRI_SAT // 1: a triangle is listed only in the cells it reaches (triangle_touches_box), 0: in every cell of its box
+#define RRTX_GRID_TRI_SAT 1
+#endif
 #ifndef RRTX_APPROX_TRI_INFLATION
 #define RRTX_APPROX_TRI_INFLATION 0.05
 #endif
 constexpr double kApproxTriInflation = RRTX_APPROX_TRI_INFLATION; // of a cell: boxes of triangles gridded without proof (fp32)
 constexpr double kGridDir2Max = 1e6; // |d|^2 up to which gridded triangles are proven (camera rays of final.txt: ~ 1e2)
+// Does the triangle (v0, v1, v2) touch the axis-aligned box [lo, hi]?  The separating-axis test (Akenine-Moeller 2001: the
+// box's three face normals, the triangle's normal, the nine cross products of edges and axes), in double, told to answer
+// "yes" whenever an axis separates by less than `margin`.  Used to keep a triangle out of the cells of its bounding box
+// that it does not reach: a mesh of cell-sized triangles lists each in ~8 cells by its box, in ~4 by this test.
+inline bool triangle_touches_box(const double v[3][3], const double lo[3], const double hi[3], double margin)
+{
+    double c[3], h[3], p[3][3];
+    for (int k = 0; k < 3; ++k) c[k] = 0.5 * (lo[k] + hi[k]), h[k] = 0.5 * (hi[k] - lo[k]) + margin;
+    for (int q = 0; q < 3; ++q)
+        for (int k = 0; k < 3; ++k) p[q][k] = v[q][k] - c[k];
+    for (int k = 0; k < 3; ++k) { // the box's face normals
+        const double mn = std::min({p[0][k], p[1][k], p[2][k]}), mx = std::max({p[0][k], p[1][k], p[2][k]});
+        if (mn > h[k] || mx < -h[k]) return false;
+    }
+    const double e[3][3] = {{p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]}, {p[2][0] - p[1][0], p[2][1] - p[1][1], p[2][2] - p[1][2]}, {p[0][0] - p[2][0], p[0][1] - p[2][1], p[0][2] - p[2][2]}};
+    auto separated = [&](const double a[3]) { // is `a` a separating axis?  (a zero axis - parallel edge and axis - separates nothing)
+        const double len = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        if (!(len > 0)) return false;
+        const double d0 = a[0] * p[0][0] + a[1] * p[0][1] + a[2] * p[0][2], d1 = a[0] * p[1][0] + a[1] * p[1][1] + a[2] * p[1][2], d2 = a[0] * p[2][0] + a[1] * p[2][1] + a[2] * p[2][2];
+        const double r = h[0] * std::fabs(a[0]) + h[1] * std::fabs(a[1]) + h[2] * std::fabs(a[2]);
+        return std::min({d0, d1, d2}) > r || std::max({d0, d1, d2}) < -r;
+    };
+    for (int q = 0; q < 3; ++q)
+        for (int k = 0; k < 3; ++k) {
+            double a[3] = {0, 0, 0}; // axis_k x e_q
+            const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            a[k1] = -e[q][k2], a[k2] = e[q][k1];
+            if (separated(a)) return false;
+        }
+    const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    return !separated(n);
+}
+
 template <typename F>
 inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<SphereCold<F>> &cold, int n_sph, int n_sph_pad, const std::vector<MovingSphereRec<F>> &ms,
                        int n_msph, const std::vector<TriangleRec<F>> &tri, int n_tri, const CameraRec<F> &cam, std::vector<uint32_t> &cell_start, std::vector<GridPrim> &cell_prims,
@@ -88,6 +124,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         int idx;
         bool is_tri;
         double e1e2, e_sum, vmax; // triangles: |e1| |e2|, |e1| + |e2|, largest vertex coordinate
+        double v[3][3];           // triangles: the three vertices the device test sees
         bool candidate;           // may be gridded at all (triangles: only where the bound holds, or under the approximate rule)
         bool proven;              // triangles: the residual bound holds
     };
@@ -124,6 +161,7 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
         for (int k = 0; k < 3; ++k) {
             const double a0 = (double)tri[i].v0[k], a1 = a0 + (double)tri[i].e1[k], a2 = a0 + (double)tri[i].e2[k];
             b.lo[k] = std::min({a0, a1, a2}), b.hi[k] = std::max({a0, a1, a2});
+            b.v[0][k] = a0, b.v[1][k] = a1, b.v[2][k] = a2;
             l1 += (double)tri[i].e1[k] * (double)tri[i].e1[k], l2 += (double)tri[i].e2[k] * (double)tri[i].e2[k];
             b.vmax = std::max({b.vmax, std::fabs(a0), std::fabs(a1), std::fabs(a2)});
         }
@@ -265,6 +303,14 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
                     for (int iy = a[1]; iy <= z[1]; ++iy)
                         for (int ix = a[0]; ix <= z[0]; ++ix) {
                             const int cidx = (iz * dims[1] + iy) * dims[0] + ix;
+                            if (boxes[i].is_tri && RRTX_GRID_TRI_SAT) {
+                                // (a hit the exact test reports lies within delta of the triangle: a point of the triangle
+                                // then lies in the hit's cell grown by delta on every side)
+                                const int ic[3] = {ix, iy, iz};
+                                double blo[3], bhi[3];
+                                for (int k = 0; k < 3; ++k) blo[k] = lo[k] + ic[k] * cell - delta[i], bhi[k] = lo[k] + (ic[k] + 1) * cell + delta[i];
+                                if (!triangle_touches_box(boxes[i].v, blo, bhi, 1e-6 * cell)) continue;
+                            }
                             if (pass == 0)
                                 count[cidx + 1] += 1;
                             else

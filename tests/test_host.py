@@ -346,3 +346,12 @@ def test_cli_batch_logic_under_thread_sanitizer(tmp_path):
         assert all(open(str(tmp_path / ("a%d.png" % i)), "rb").read() == single[s] for i, s in enumerate(names))
     r = subprocess.run([exe] + small + ["-G", "2", "-i", names[1], "-o", str(tmp_path / "x.png"), "-i", str(bad), "-o", str(tmp_path / "y.png"), "-i", names[0], "-o", str(tmp_path / "z.png")], capture_output=True, timeout=600)
     assert r.returncode == 3 and b"ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_triangle_box_overlap_is_conservative(tmp_path):
+    """rrtx_grid.h lists a triangle only in the cells it reaches (triangle_touches_box): the test may answer "touches" too
+    often, never too rarely - random triangles (needles, slivers, collinear) against random boxes near and far."""
+    exe = str(tmp_path / "tri_box_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "tri_box_check.cpp")], check=True)
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
