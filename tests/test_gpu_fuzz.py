@@ -7,7 +7,7 @@ finishes the parked paths, renders it through the C-ABI in the list scan and in 
 shards, and compares with the oracle's frame: equal in every bit (accelerated fp32 scenes whose triangles were gridded
 under the approximate rule: at most one pixel in 10^4, include/rrtx.h RRTX_FLAG_EXACT_ACCEL).
 
-RRTX_FUZZ_CASES (default 16 per precision, a dozen seconds) scales it: the round-2 campaign ran 400 per precision;
+RRTX_FUZZ_CASES (default 16 per precision, a few seconds) scales it: the round-2 campaigns ran up to 3000 per precision;
 RRTX_FUZZ_SEED moves it elsewhere.
 """
 import os
