@@ -180,9 +180,9 @@ template <typename F> struct ScanType<F, true> {
 // The ray of lane `src` against every primitive, by all 64 lanes of the wave: lane l tests primitives l, l + 64, ...
 // with the exact test; a butterfly picks the winner by consider()'s order-independent rule, which is the answer
 // of the sequential scan for any finite ray.  Every lane returns the result.
-template <typename F, typename HotTab> __device__ __forceinline__ HitInfo<F> wave_exact_scan(const KernelParams<F> &P, HotTab hot, const Path<F> &path, int src, int lane, F t_min)
+template <typename F, bool SO = false, typename HotTab> __device__ __forceinline__ HitInfo<F> wave_exact_scan(const KernelParams<F> &P, HotTab hot, const Path<F> &path, int src, int lane, F t_min)
 {
-    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph; // (the loop's bounds: the real ones)
     Path<F> rp;
     rp.o = mk<F>(__shfl(path.o.x, src), __shfl(path.o.y, src), __shfl(path.o.z, src));
     rp.d = mk<F>(__shfl(path.d.x, src), __shfl(path.d.y, src), __shfl(path.d.z, src));
@@ -193,19 +193,19 @@ template <typename F, typename HotTab> __device__ __forceinline__ HitInfo<F> wav
     PendingRoot<F> pend = {-1, 0, 0};
     for (int idx = lane; idx < tri_base + P.n_tri; idx += 64) {
         if (idx >= P.n_sph && idx < msph_base) continue; // (padding records)
-        test_primitive<F>(P, hot, idx, rp, ra, t_min, hb, pend);
+        test_primitive<F, SO>(P, hot, idx, rp, ra, t_min, hb, pend);
     }
-    resolve_pending<F>(pend, ra, t_min, tri_base, hb);
+    resolve_pending<F>(pend, ra, t_min, SO ? kNoTriangles : tri_base, hb);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const F ot = __shfl_xor(hb.t, off);
         const int oi = __shfl_xor(hb.idx, off);
-        if (oi >= 0) consider<F>(ot, oi, tri_base, hb);
+        if (oi >= 0) consider<F>(ot, oi, SO ? kNoTriangles : tri_base, hb);
     }
     return hb;
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -241,7 +241,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     const HotPtr sph_scalar = (HotPtr)ScanType<F, FILTER>::table(P);
 
     const F t_min = (F)0.001; // rrt.cpp:32 typing
-    const int n_sph = P.n_sph, n_sph_pad = P.n_sph_padded, n_msph = P.n_msph, n_tri = P.n_tri;
+    const int n_sph = P.n_sph, n_sph_pad = P.n_sph_padded, n_msph = SO ? 0 : P.n_msph, n_tri = SO ? 0 : P.n_tri; // (SO: their loops fold away)
     const int msph_base = n_sph_pad, tri_base = n_sph_pad + n_msph;
 
     // wave-uniform task pool
@@ -331,9 +331,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 waiting &= waiting - 1ull;
                 HitInfo<F> hb;
                 if (ACCEL == 2)
-                    hb = wave_exact_scan<F>(P, hot_lds, path, src, lane, t_min);
+                    hb = wave_exact_scan<F, SO>(P, hot_lds, path, src, lane, t_min);
                 else
-                    hb = wave_exact_scan<F>(P, P.sph_hot, path, src, lane, t_min);
+                    hb = wave_exact_scan<F, SO>(P, P.sph_hot, path, src, lane, t_min);
                 if (lane == src) best = hb, walk_cell = kCoopDone, n_scanned += 1;
             }
         }
@@ -570,9 +570,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (in_walk && walk_cell == kCoopDone)
                     r = kWalkDone; // a far ray the wave resolved at the top of this iteration: `best` is final
                 else if (ACCEL == 2)
-                    r = accel_closest_hit<F>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
+                    r = accel_closest_hit<F, SO>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 else
-                    r = accel_closest_hit<F>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
+                    r = accel_closest_hit<F, SO>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice);
                 need_scan = r == kWalkNeedsScan;
                 if (r == kWalkFarScan) walk_cell = kCoopWait; // (waits, as a walk in progress, for the next top of the loop)
                 still_walking = in_walk = r == kWalkGoesOn || r == kWalkFarScan;
@@ -748,7 +748,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
 
             // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
             RRTX_SEC(5); // shading
-            if (!still_walking) done = shade<F>(P, best, path, rng, radiance);
+            if (!still_walking) done = shade<F, SO>(P, best, path, rng, radiance);
             } // max_depth > 0
 
             RRTX_SEC(6); // sample / task bookkeeping, stores
@@ -1272,10 +1272,17 @@ template <typename F> __global__ void __launch_bounds__(256) deinterleave_kernel
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SO>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
+}
+// the accelerated variants (render and resume passes): tables in LDS or in HBM, scenes of spheres alone or of every kind
+template <typename F, bool FILTER, bool RESUME> hipError_t launch_accel(const KernelParams<F> &P, int grid_blocks, size_t alds, hipStream_t stream)
+{
+    const bool spheres_only = P.n_msph == 0 && P.n_tri == 0;
+    if (alds) return spheres_only ? launch_variant<F, FILTER, 0, false, 2, RESUME, true>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 2, RESUME, false>(P, grid_blocks, alds, stream);
+    return spheres_only ? launch_variant<F, FILTER, 0, false, 1, RESUME, true>(P, grid_blocks, 0, stream) : launch_variant<F, FILTER, 0, false, 1, RESUME, false>(P, grid_blocks, 0, stream);
 }
 // bytes of LDS the accelerated variant wants for its tables (0: they stay in HBM)
 template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
@@ -1289,8 +1296,7 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
     if (P.grid_cell_start) { // accelerated closest hit; the scan (scalar loads) is its fallback
         const size_t alds = accel_lds_bytes<F>(P);
         if (P.verify_lists) return launch_variant<F, true, 0, true, 1>(P, grid_blocks, 0, stream);
-        if (!filter) return alds ? launch_variant<F, false, 0, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, false, 0, false, 1>(P, grid_blocks, 0, stream);
-        return alds ? launch_variant<F, true, 0, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, true, 0, false, 1>(P, grid_blocks, 0, stream);
+        return filter ? launch_accel<F, true, false>(P, grid_blocks, alds, stream) : launch_accel<F, false, false>(P, grid_blocks, alds, stream);
     }
     if (P.verify_lists) return launch_variant<F, true, 0, true, 0>(P, grid_blocks, 0, stream); // test build: filter + scalar loads + list check
     if (!filter) return launch_variant<F, false, 0, false, 0>(P, grid_blocks, 0, stream); // the exact scan is the fallback: scalar loads only
@@ -1315,17 +1321,7 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
 template <typename F> hipError_t launch_resume(const KernelParams<F> &P, bool filter, int grid_blocks, hipStream_t stream)
 {
     const size_t alds = accel_lds_bytes<F>(P);
-    if (!filter) {
-        if (alds)
-            hipLaunchKernelGGL((render_kernel<F, false, 0, false, 2, true>), dim3(grid_blocks), dim3(kBlockThreads), alds, stream, P);
-        else
-            hipLaunchKernelGGL((render_kernel<F, false, 0, false, 1, true>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
-    }
-    else if (alds)
-        hipLaunchKernelGGL((render_kernel<F, true, 0, false, 2, true>), dim3(grid_blocks), dim3(kBlockThreads), alds, stream, P);
-    else
-        hipLaunchKernelGGL((render_kernel<F, true, 0, false, 1, true>), dim3(grid_blocks), dim3(kBlockThreads), 0, stream, P);
-    hipError_t e = hipGetLastError();
+    hipError_t e = filter ? launch_accel<F, true, true>(P, grid_blocks, alds, stream) : launch_accel<F, false, true>(P, grid_blocks, alds, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tail_sum_kernel<F>, dim3(256), dim3(256), 0, stream, P);
     return hipGetLastError();
@@ -1367,6 +1363,7 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
     if (P.grid_cell_start) {
         const size_t alds = accel_lds_bytes<F>(P);
+        // (the variants for scenes of spheres alone are compiled under the same launch bounds: the same occupancy)
         if (!filter)
             return alds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 2>, kBlockThreads, alds)
                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 1>, kBlockThreads, 0);
