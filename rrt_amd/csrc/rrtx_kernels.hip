@@ -565,7 +565,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             if (ACCEL != 0) RRTX_SEC(7); // (developer builds: the grid walk, apart from the LIST passes of section 2)
             if (ACCEL != 0) {
                 const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
-                const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : C.grid.walk_slice; // (the macro: experiments)
+                // (tables in LDS: 4 cells, a constant the loop is compiled for - 37.8 -> 37.5 ms -; the grids that ask for 16, large and
+                // mostly empty, live in HBM; the macro: experiments)
+                const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : (ACCEL == 2 ? 4 : C.grid.walk_slice);
                 int r;
                 if (in_walk && walk_cell == kCoopDone)
                     r = kWalkDone; // a far ray the wave resolved at the top of this iteration: `best` is final
