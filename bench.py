@@ -58,8 +58,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK = 0.5        # VALU wave-instructions per clock per SIMD: a wave64 instruction occupies the 32-lane fp32 pipe for 2 clocks
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9       # nominal; a PMC pass measures the real one (GRBM_GUI_ACTIVE / 8 XCDs / duration)
-LIST_KERNEL = "render_kernel<float, true, 1, false, 0, false>"
-ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false>"
+# Names as rocprofv3 prints them, up to and including the RESUME = false argument - prefixes, so that template
+# parameters added behind it (SO: scenes of spheres alone) do not lose the match (tests/test_cabi.py checks both
+# against the library's symbols): the list-scan render kernel of final.txt and the accelerated one.
+LIST_KERNEL = "render_kernel<float, true, 1, false, 0, false"
+ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false"
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -137,10 +140,11 @@ def pmc_pass(counters, rrt_args, want_kernel, timeout=100):
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
         if r.returncode != 0:
             return None
-        acc, n, dur = {}, {}, []
+        acc, n, dur, name = {}, {}, [], None
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if want_kernel in row["Kernel_Name"]:
+                    name = row["Kernel_Name"]
                     c = row["Counter_Name"]
                     acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
                     n[c] = n.get(c, 0) + 1
@@ -152,6 +156,7 @@ def pmc_pass(counters, rrt_args, want_kernel, timeout=100):
             return None
         res = {c: acc[c] / n[c] for c in acc}  # one row per (dispatch, counter): the mean over this kernel's dispatches = per launch
         res["launches"] = max(n.values())
+        res["kernel_name"] = name
         if dur:
             res["duration_ms"] = sum(dur) / len(dur)
         return res
@@ -391,13 +396,15 @@ def main():
 
         # ---- the binding unit: VALU issue
         clock = CLOCK_HZ
-        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD", "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL, "kernel_ms": round(kernel_ms, 3)}
+        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD", "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL + ", ...>", "kernel_ms": round(kernel_ms, 3)}
         if pmc and pmc.get("list_scan"):
             per_clk, lanes, ghz = valu_numbers(pmc["list_scan"])
             if ghz:
                 clock = ghz * 1e9
+            if pmc["list_scan"].get("kernel_name"):
+                roof["kernel"] = pmc["list_scan"]["kernel_name"].split("(")[0].replace("void ", "")
             roof.update({"achieved": round(per_clk, 4), "frac": round(per_clk / VALU_PEAK, 4), "valu_lane_utilisation": round(lanes, 4) if lanes else None,
-                         "shader_clock_GHz": round(ghz, 3) if ghz else None, "counters": {k: v for k, v in pmc["list_scan"].items()}, "source": pmc["source"], "kernel_source_sha": pmc.get("kernel_source_sha")})
+                         "shader_clock_GHz": round(ghz, 3) if ghz else None, "counters": {k: v for k, v in pmc["list_scan"].items() if k != "kernel_name"}, "source": pmc["source"], "kernel_source_sha": pmc.get("kernel_source_sha")})
             roof["traffic"] = (pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) if "hbm_read_bytes" in pmc else None
             if "hbm_read_bytes" in pmc:
                 roof["traffic_detail"] = {"read_bytes": pmc["hbm_read_bytes"], "write_bytes": pmc["hbm_write_bytes"], "hbm_GBs": round((pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) / (kernel_ms * 1e-3) / 1e9, 1),

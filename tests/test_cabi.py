@@ -129,3 +129,21 @@ def test_integration_md_shows_the_file_that_is_compiled():
     src = open(os.path.join(ROOT, "oracle", "ref_dropin.cpp")).read()
     body = src[src.index('#include "rrt.h"'):]
     assert body in doc
+
+
+def test_bench_profiles_the_kernels_that_exist():
+    """bench.py finds its two kernels in rocprofv3's output by name (LIST_KERNEL, ACCEL_KERNEL): each must match exactly one
+    render kernel among the library's symbols per scene class - a template parameter added to render_kernel must not
+    silently turn the roofline into its fallback."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_names", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = subprocess.run(["nm", "-C", "--defined-only", os.path.join(ROOT, "rrt_amd", "librrtx.so")], capture_output=True, text=True, check=True).stdout
+    kernels = sorted({line.split(" ", 2)[2].split("(")[0].replace("void ", "") for line in out.splitlines() if " rrtx::render_kernel<" in line and "__device_stub__" not in line})
+    assert len(kernels) >= 20
+    lists = [k for k in kernels if bench.LIST_KERNEL in k]
+    accel = [k for k in kernels if bench.ACCEL_KERNEL in k]
+    assert len(lists) == 1, lists  # the list scan has no variants by scene class
+    assert len(accel) == 2 and all(k.endswith(("true>", "false>")) for k in accel), accel  # scenes of spheres alone / of every kind
