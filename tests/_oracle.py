@@ -313,10 +313,12 @@ def random_scene(rng, path):
 def crowded_scene(rng, path):
     """Random scenes with enough primitives for the acceleration grid (40 - 600): spheres over four orders of magnitude of
     size - clusters of tiny ones, a few that dwarf a cell, some far from everything -, moving spheres, and one or two small
-    meshes instanced several times under random transforms; a camera anywhere, sometimes inside the crowd, sometimes far away."""
+    meshes instanced several times under random transforms (a third of the scenes: spheres alone); a camera anywhere, sometimes
+    inside the crowd, sometimes far away."""
     u = lambda lo, hi: float(rng.uniform(lo, hi))
     lines = []
     far_cam = rng.random() < 0.2
+    spheres_only = rng.random() < 0.35  # (neither moving spheres nor meshes: the kernels' variants for such scenes)
     span = u(2, 12)  # the crowd lives in [-span, span]^2 x [0, span / 2]
     cd = u(40, 400) if far_cam else u(0.5, 2.5) * span
     ang, el = u(0, 2 * np.pi), u(0.05, 1.2)
@@ -341,14 +343,14 @@ def crowded_scene(rng, path):
         y = r if rng.random() < 0.6 else u(0, span / 2)
         if kind > 0.97:
             x, z = x * 8, z * 8  # far from everything
-        if rng.random() < 0.06:
+        if rng.random() < 0.06 and not spheres_only:
             lines.append("msphere %r %r %r  %r %r %r  0.0 1.0  %r %s" % (x, y, z, x + u(-1, 1) * r * 3, y + u(0, 1) * r * 3, z + u(-1, 1) * r * 3, r, pick()))
         else:
             lines.append("sphere %r %r %r %r %s" % (x, y, z, r if rng.random() > 0.02 else -r, pick()))
     if rng.random() < 0.3:  # a cluster of coincident / nested spheres
         cx, cz, cr = u(-span, span), u(-span, span), base
         lines += ["sphere %r %r %r %r g" % (cx, cr, cz, cr), "sphere %r %r %r %r g" % (cx, cr, cz, -0.9 * cr), "sphere %r %r %r %r m" % (cx, cr, cz, cr), "sphere %r %r %r %r r" % (cx, cr, cz, 0.5 * cr)]
-    n_obj = int(rng.integers(0, 3))
+    n_obj = 0 if spheres_only else int(rng.integers(0, 3))
     for _ in range(n_obj):
         nu, nv = int(rng.integers(2, 7)), int(rng.integers(3, 12))
         verts = [(np.sin(np.pi * i / nu) * np.cos(2 * np.pi * j / nv), np.cos(np.pi * i / nu), np.sin(np.pi * i / nu) * np.sin(2 * np.pi * j / nv)) for i in range(nu + 1) for j in range(nv)]
