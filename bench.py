@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accel", action="store_true", help="skip the extra use_bvh measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C4 / C5-on-one-GPU sub-results")
+    ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip timing the same workload on rank 0 alone")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (a committed profile is used if it matches the device code)")
     args = ap.parse_args()
 
@@ -375,6 +376,33 @@ def main():
         except Exception as e:
             configs["C3_native_group"] = {"error": repr(e)}
 
+    # ---- N > 1: the SAME workload on one GPU, timed by rank 0 inside this job (the others wait): what `value` is N times of
+    # when the split is perfect.  (The N = 1 bench line is configuration 3; the N > 1 default is configuration 5.)
+    one_gpu = None
+    if world > 1 and not args.no_one_gpu:
+        barrier()
+        if rank == 0:
+            try:
+                r1 = rrt_amd.Rrt(W, H, spp, DEPTH, use_bvh=False, fp64=False, device=device_index, collect_stats=False)
+                r1.set_scene(rrt_amd.Scene(SCENE, W, H))
+                whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                r1.render_device(whole.data_ptr(), stream)
+                torch.cuda.synchronize()
+                n1 = 2
+                t0 = time.perf_counter()
+                for _ in range(n1):
+                    r1.render_device(whole.data_ptr(), stream)
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t0) / n1 * 1e3
+                one_gpu = {"ms_per_step": round(ms1, 3), "value": round(W * H * spp / (ms1 * 1e-3) / 1e6, 2), "unit": "Msamples/s", "steps": n1,
+                           "note": "the whole frame of this line's workload on rank 0's GPU alone, timed inside the same job while the other ranks wait"}
+                r1.close()
+                del whole
+            except Exception as e:
+                one_gpu = {"error": repr(e)}
+        barrier()
+
     # per-rank kernel statistics -> whole-job numbers
     vec = torch.tensor([float(st["bytes_algorithmic"]), st["kernel_ms_sum"] / max(1, st["renders"]), float(st["segments"]), float(st["prim_tests"]), float(st["scanned_segments"]),
                         float(st["candidates"])], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -444,6 +472,8 @@ def main():
         if kernel_only is not None:
             line["kernel_only_ms_per_step"] = round(kernel_only, 3)
             line["gather_ms_per_step"] = round(max(0.0, ms_per_step - kernel_only), 3)
+        if one_gpu is not None:
+            line["one_gpu_same_workload"] = one_gpu
         if accel is not None:
             line["accelerated"] = accel
         if configs is not None:

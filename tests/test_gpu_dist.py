@@ -161,3 +161,5 @@ def test_bench_line_of_a_two_rank_run(gpu):
     assert j["kernel_only_ms_per_step"] > 0 and j["gather_ms_per_step"] >= 0
     assert j["roofline"]["bound"] == "valu_issue" and 0 < j["roofline"]["frac"] <= 1 and "logical_hbm" in j["roofline"]
     assert "cpu_baseline" not in j  # rank 0 at N = 1 only
+    one = j["one_gpu_same_workload"]  # the same frame on rank 0's GPU alone, inside the same job
+    assert "error" not in one and one["ms_per_step"] > 0 and abs(one["value"] - 3840 * 2160 * 24 / (one["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * one["value"]
