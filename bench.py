@@ -12,11 +12,15 @@ Workloads (BASELINE.json `configs`):
   N = 1   C3 = scenes/final.txt 1200x800 spp 500 d 50 fp32, brute-force list scan (the mode north_star names and
           the roofline is defined for) - the configuration the metric is quoted on.  The same line carries, timed by
           this run: `accelerated` (C3 with use_bvh, the CLI's default mode) and `configs` = C2 (test1 1200x800
-          spp 10), C4 (final fp64), C5 on ONE GPU (final 3840x2160 spp 1000), each in both modes.
+          spp 10), C4 (final fp64), C5 on ONE GPU (final 3840x2160 spp 1000), each in both modes, and `mesh` (a 27 072-
+          triangle mesh).
   N > 1   C5 = scenes/final.txt 3840x2160 spp 1000 fp32 cut into row tiles over the N ranks ("scaling": "strong":
           the total is BASELINE.json's 8-GPU job whatever N is), one RCCL gather to rank 0 per step; the line reports
-          the kernel-only time (slowest rank) next to the gather-inclusive step time.  `--strong-c3` shards C3
-          instead (9.7 ms of work per GPU at N = 8), `--weak` keeps 480 M samples per GPU (C3 at spp 500 x N).
+          the kernel-only time (slowest rank) next to the gather-inclusive step time, `config.rccl` says what RCCL saw
+          (ranks, backend, version, every rank's device), `one_gpu_same_workload` times the whole C5 frame on rank 0's GPU
+          alone inside the job, and `strong_c3` splits configuration 3 the same way (north_star states its 7.5 x on C3:
+          9.7 ms of work per GPU at N = 8) next to C3 whole on rank 0's GPU.  `--strong-c3` makes C3 the line's own
+          workload, `--weak` keeps 480 M samples per GPU (C3 at spp 500 x N).
 The image is bit-identical for every N and tile size (tests/test_gpu_configs.py, tests/test_gpu_group.py).
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields:
@@ -224,6 +228,7 @@ def main():
     ap.add_argument("--no-accel", action="store_true", help="skip the extra use_bvh measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C4 / C5-on-one-GPU sub-results")
     ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip timing the same workload on rank 0 alone")
+    ap.add_argument("--no-strong-c3", action="store_true", help="N > 1: skip the extra split of configuration 3 (the `strong_c3` sub-result)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 passes (a committed profile is used if it matches the device code)")
     args = ap.parse_args()
 
@@ -276,11 +281,33 @@ def main():
     backend = os.environ.get("RRTX_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(device_index)
+    rccl_info = None
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
+        # a communicator that cannot be built ends the run, non-zero, with RCCL's own words on stderr: no re-exec, no silent
+        # fall-back to another backend (RRTX_BENCH_BACKEND=gloo is something the caller asks for, see above)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+                probe = torch.ones(1, device=torch.device("cuda", device_index))
+                dist.all_reduce(probe)  # builds the communicator now: an RCCL failure surfaces here, with its text
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            else:
+                dist.init_process_group(backend)
+        except Exception as e:
+            sys.stderr.write("bench.py: rank %d: the %s process group could not be built: %r\n" % (rank, backend, e))
+            sys.stderr.flush()
+            os._exit(3)
+        # what RCCL saw, for the reader of the line: ranks, backend, every rank's device
+        mine = {"rank": rank, "local_rank": local_rank, "ordinal": device_index, "name": torch.cuda.get_device_name(device_index), "pid": os.getpid(), "host": os.uname().nodename}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        rccl_info = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver if backend == "nccl" else None, "devices": everyone,
+                     "distinct_devices": len({(d["host"], d["ordinal"]) for d in everyone})}
     dev = torch.device("cuda", device_index)
 
     import rrt_amd
@@ -334,7 +361,8 @@ def main():
         accel = {"value": round(W * H * spp / (elapsed_a / args.steps) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(elapsed_a / args.steps * 1e3, 3),
                  "kernel_ms": round(sta["kernel_ms_sum"] / max(1, sta["renders"]), 3), "grid_cells": sta["accel_cells"],
                  "note": "use_bvh = 1 (the CLI's default, as the reference's BVH is): closest hit through a uniform grid + always-list, exact test and tie rules of the list scan, "
-                         "image bit-identical (tests/test_gpu_configs.py); segments fall back to the list scan only for rays outside the grid's proven range (DESIGN.md 3b)"}
+                         "image bit-identical for spheres, moving spheres and fp64 meshes - this scene: yes (tests/test_gpu_configs.py; fp32 triangle meshes are gridded under a stated "
+                         "tolerance, rrtx_stats.accel_exact = 0, `rrt -X` / -b for the list scan's bits); segments fall back to the list scan only for rays outside the grid's proven range (DESIGN.md 3b)"}
         if pmc and pmc.get("accelerated"):
             pc, lanes, _ = valu_numbers(pmc["accelerated"])
             accel["valu_issue_frac"] = round(pc / VALU_PEAK, 4)
@@ -370,7 +398,8 @@ def main():
                 ds.append(dict(g.stats))
             best = min(ds, key=lambda d: d["device_ms"])
             configs["C3_native_group"] = {"n_devices": best["n_devices"], "rccl": best["rccl"], "render_ms": round(best["render_ms"], 3), "device_ms": round(best["device_ms"], 3),
-                                          "gather_ms": round(best["gather_ms"], 3), "gathered_bytes": best["gathered_bytes"],
+                                          "gather_ms": round(best["gather_ms"], 3), "gathered_bytes": best["gathered_bytes"], "rccl_comms": best["rccl_comms"], "rccl_version": best["rccl_version"],
+                                          "devices": best["devices"],
                                           "note": "rrtx_group_render_device: one process, ncclCommInitAll + grouped ncclSend / ncclRecv to device 0 + de-interleave; device_ms = first launch -> assembled frame"}
             g.close()
         except Exception as e:
@@ -401,6 +430,43 @@ def main():
                 del whole
             except Exception as e:
                 one_gpu = {"error": repr(e)}
+        barrier()
+
+    # ---- N > 1 on configuration 5: the same job ALSO splits configuration 3 (north_star's "1200x800 spp=500 ... >= 7.5 x at 8
+    # GPUs" is stated on C3), so that one driver run reports both: shards of C3 + gather, and C3 whole on rank 0's GPU alone
+    strong_c3 = None
+    if world > 1 and wl_name == "C5" and not args.no_strong_c3:
+        w3, h3, s3 = C3
+        if args.spp > 0:
+            s3 = args.spp  # (non-headline runs: rehearsals, tests)
+        s3r = ShardedRenderer(SCENE, w3, h3, s3, DEPTH, fp64=False, tile_rows=args.tile_rows, device=dev, collect_stats=False)
+        n3 = max(args.steps, 10)
+        e3, st3 = timed(s3r, n3, 2)
+        k3, _ = timed(s3r, n3, 0, gather=False)
+        strong_c3 = {"workload": "C3: scenes/final.txt %dx%d spp=%d d=%d fp32, list scan, row-tile shards x%d + one gather per step" % (w3, h3, s3, DEPTH, world), "steps": n3,
+                     "ms_per_step": round(e3 / n3 * 1e3, 3), "kernel_only_ms_per_step": round(k3 / n3 * 1e3, 3), "value": round(w3 * h3 * s3 / (e3 / n3) / 1e6, 2), "unit": "Msamples/s"}
+        del s3r
+        barrier()
+        if rank == 0:
+            try:
+                r1 = rrt_amd.Rrt(w3, h3, s3, DEPTH, use_bvh=False, fp64=False, device=device_index, collect_stats=False)
+                r1.set_scene(rrt_amd.Scene(SCENE, w3, h3))
+                whole = torch.empty((h3, w3, 3), dtype=torch.float32, device=dev)
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                r1.render_device(whole.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n3):
+                    r1.render_device(whole.data_ptr(), stream)
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t0) / n3 * 1e3
+                strong_c3["one_gpu_ms_per_step"] = round(ms1, 3)
+                strong_c3["speedup_vs_one_gpu"] = round(ms1 / (e3 / n3 * 1e3), 3)
+                strong_c3["north_star_target"] = ">= 7.5 at 8 GPUs"
+                r1.close()
+                del whole
+            except Exception as e:
+                strong_c3["one_gpu_error"] = repr(e)
         barrier()
 
     # per-rank kernel statistics -> whole-job numbers
@@ -472,8 +538,12 @@ def main():
         if kernel_only is not None:
             line["kernel_only_ms_per_step"] = round(kernel_only, 3)
             line["gather_ms_per_step"] = round(max(0.0, ms_per_step - kernel_only), 3)
+        if rccl_info is not None:
+            line["config"]["rccl"] = rccl_info
         if one_gpu is not None:
             line["one_gpu_same_workload"] = one_gpu
+        if strong_c3 is not None:
+            line["strong_c3"] = strong_c3
         if accel is not None:
             line["accelerated"] = accel
         if configs is not None:

@@ -226,8 +226,10 @@ void rrtx_destroy(rrtx_ctx *ctx);
 
 /* The marshalling half of Rrt::render (rrt.cu:217-270): packs the tables into the device
  * layout and uploads them.  Replaces create_world<<<1,1>>>.  May be called again to swap
- * scenes on a live context (it waits for the device to be idle first; the device buffers of
- * the previous scene are reused and only grow: 0.3 ms per call for final.txt at 1280x720). */
+ * scenes on a live context (it waits for THIS context's renders to finish first - the stop event of
+ * every render enqueued through it, on whatever stream, and its own stream - not for the device:
+ * other contexts and a host application's streams keep running; the device buffers of the previous
+ * scene are reused and only grow: 0.3 ms per call for final.txt at 1280x720). */
 int rrtx_set_scene(rrtx_ctx *ctx, const rrtx_scene_desc *scene);
 
 /* Rows of the frame this context renders (global row numbers, ascending; row 0 = bottom of
@@ -272,6 +274,13 @@ typedef struct rrtx_group rrtx_group;
  * decomposition on fewer GPUs, for tests - RCCL cannot build a communicator over duplicates, the row
  * blocks then move with device-to-device copies instead.  Rejected without this flag. */
 #define RRTX_GROUP_REHEARSAL 1
+/* RCCL greets on STDOUT when a communicator is built ("RCCL version : ..."), and stdout is where `rrt` prints its PPM
+ * (main.cpp:142).  rrtx_group_create therefore points file descriptor 1 at stderr while ncclCommInitAll runs (dup2 /
+ * restore).  That is PROCESS-WIDE and not synchronised with other threads: bytes another thread writes to stdout in
+ * that window land on stderr.  A caller that owns stdout and writes to it from other threads passes this flag and
+ * does the diversion itself, or creates its groups before those threads exist (`rrt` does: a group is created by the
+ * first job of its worker, before any writer task). */
+#define RRTX_GROUP_KEEP_STDOUT 2
 
 typedef struct rrtx_group_stats {
     int32_t n_devices;
@@ -284,6 +293,11 @@ typedef struct rrtx_group_stats {
     uint64_t samples, segments, prim_tests, bytes_algorithmic; /* summed over the devices      */
     uint64_t gathered_bytes; /* bytes that crossed to rank 0 (its own block included)           */
     int32_t sample_chunk, accel_cells;
+    int32_t accel_exact;     /* as rrtx_stats.accel_exact, 0 if any member renders under the approximate rule */
+    int32_t rccl_version;    /* ncclGetVersion() of the library the communicators were built with (0: none) */
+    int32_t rccl_comms;      /* communicators alive in this group (= n_devices, 0 in a rehearsal)         */
+    int32_t devices[16];     /* HIP ordinal of each member (first 16)                                    */
+    int32_t reserved;
 } rrtx_group_stats;
 
 /* params: as for rrtx_create; device / shard_rank / shard_count are ignored (set per member).
@@ -308,6 +322,11 @@ int rrtx_scene_load(const char *path, int image_width, int image_height, int fp6
  * (scene.h:222,289,433-441: 1 = obj errors, 2 = cannot open, 3 = unknown material, 4 = scene
  * sanity). */
 int rrtx_scene_exit_code(void);
+/* The message rrtx_scene_load printed on stderr for that failure (the reference's own text, scene.h:222,289,433-441;
+ * "" if the last load on this thread succeeded).  rrtx_scene_load_quiet() is rrtx_scene_load() without the print:
+ * for callers that parse on a helper thread and want the message in their own log, in order (`rrt` batches). */
+const char *rrtx_scene_error(void);
+int rrtx_scene_load_quiet(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out);
 void rrtx_scene_free(rrtx_scene *s);
 /* Borrowed view of the parsed tables, valid until rrtx_scene_free. */
 int rrtx_scene_describe(const rrtx_scene *s, rrtx_scene_desc *out);

@@ -132,15 +132,23 @@ class GroupStats(C.Structure):  # rrtx_group_stats
         ("gathered_bytes", C.c_uint64),
         ("sample_chunk", C.c_int32),
         ("accel_cells", C.c_int32),
+        ("accel_exact", C.c_int32),
+        ("rccl_version", C.c_int32),
+        ("rccl_comms", C.c_int32),
+        ("devices", C.c_int32 * 16),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "kernel_ms"}
-        d["kernel_ms"] = list(self.kernel_ms)[: max(1, min(16, self.n_devices))]
+        n = max(1, min(16, self.n_devices))
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("kernel_ms", "devices", "reserved")}
+        d["kernel_ms"] = list(self.kernel_ms)[:n]
+        d["devices"] = list(self.devices)[:n]
         return d
 
 
 GROUP_REHEARSAL = 1
+GROUP_KEEP_STDOUT = 2
 
 
 def _sig(name, restype, argtypes):
@@ -174,6 +182,8 @@ _sig("rrtx_group_render", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(GroupStats
 _sig("rrtx_group_render_device", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(GroupStats)])
 _sig("rrtx_scene_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)])
 _sig("rrtx_scene_exit_code", C.c_int, [])
+_sig("rrtx_scene_error", C.c_char_p, [])
+_sig("rrtx_scene_load_quiet", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)])
 _sig("rrtx_scene_free", None, [C.c_void_p])
 _sig("rrtx_scene_describe", C.c_int, [C.c_void_p, C.POINTER(SceneDesc)])
 _sig("rrtx_scene_counts", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])

@@ -362,11 +362,14 @@ extern "C" {
 
 int rrtx_scene_exit_code(void) { return g_exit_code; }
 
-int rrtx_scene_load(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out)
+const char *rrtx_scene_error(void) { return g_scene_error.c_str(); }
+
+static int scene_load(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out, bool print)
 {
     if (!out) return RRTX_E_INVALID;
     *out = nullptr;
     g_exit_code = 0;
+    g_scene_error.clear();
     if (!path || image_width < 1 || image_height < 1) return RRTX_E_INVALID;
     rrtx_scene *s = new rrtx_scene();
     s->fp64 = fp64 ? 1 : 0;
@@ -380,12 +383,15 @@ int rrtx_scene_load(const char *path, int image_width, int image_height, int fp6
         delete s;
         g_exit_code = e.exit_code;
         g_scene_error = e.what;
-        fprintf(stderr, "%s\n", e.what.c_str());
+        if (print) fprintf(stderr, "%s\n", e.what.c_str());
         return e.exit_code == 2 ? RRTX_E_IO : RRTX_E_PARSE;
     }
     *out = s;
     return RRTX_OK;
 }
+
+int rrtx_scene_load(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out) { return scene_load(path, image_width, image_height, fp64, out, true); }
+int rrtx_scene_load_quiet(const char *path, int image_width, int image_height, int fp64, rrtx_scene **out) { return scene_load(path, image_width, image_height, fp64, out, false); }
 
 void rrtx_scene_free(rrtx_scene *s) { delete s; }
 

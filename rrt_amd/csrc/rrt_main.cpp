@@ -15,6 +15,8 @@
 //   -G <gpus>                    several devices of the node, one process: a frame is cut into row tiles over them and
 //                                gathered with RCCL (rrtx_group); a batch of >= gpus scenes is dealt out scene by scene
 //   -E                           rehearsal of -G on fewer devices than members (they share what is there)
+//   -X                           exact acceleration: fp32 triangle meshes stay out of the grid (RRTX_FLAG_EXACT_ACCEL), so that
+//                                the image equals `-b`'s bit for bit also for them (spheres and fp64 meshes always do)
 #include <unistd.h>
 
 #include <atomic>
@@ -67,6 +69,7 @@ static void usage(const char *arg)
     std::cerr << "  -G <gpus>           : use this many devices, starting at -D: a frame is cut into row tiles (-T) and gathered\n";
     std::cerr << "                        over RCCL; a batch of at least as many scenes is dealt out scene by scene instead\n";
     std::cerr << "  -E                  : rehearsal: let the -G members share the devices present (tests)\n";
+    std::cerr << "  -X                  : exact acceleration: fp32 triangle meshes are not gridded (same bits as -b; slower)\n";
     std::exit(1);
 }
 
@@ -158,12 +161,13 @@ struct Worker {
     struct Parsed {
         rrtx_scene *scene = nullptr;
         int rc = 0, exit_code = 0;
+        std::string message; // the parser's diagnostic: printed with the job's own block of stderr lines, not by the helper thread
     };
     Parsed parse(const Job &job) const
     {
         Parsed p;
-        p.rc = rrtx_scene_load(job.scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &p.scene);
-        if (p.rc) p.exit_code = rrtx_scene_exit_code(); // (thread-local: read on the thread that parsed)
+        p.rc = rrtx_scene_load_quiet(job.scene_file.c_str(), prm.image_width, prm.image_height, kFp64, &p.scene);
+        if (p.rc) p.exit_code = rrtx_scene_exit_code(), p.message = rrtx_scene_error(); // (thread-local: read on the thread that parsed)
         return p;
     }
 
@@ -214,6 +218,7 @@ struct Worker {
             // the reference exits on the spot with scene.h's code (1 obj errors, 2 cannot open, 3 unknown material, 4 sanity);
             // in a batch: no further scenes are started, what is in flight is written, the first such code is the exit code
             int code = parsed.exit_code;
+            if (!parsed.message.empty()) log(parsed.message + "\n");
             int expected = 0;
             shared->exit_code.compare_exchange_strong(expected, code ? code : 1);
             shared->stop = true;
@@ -271,12 +276,12 @@ struct Worker {
         // rrt.cu:195-202,261
         err << "HIP Runtime Version " << rrtx_runtime_version() << "\n";
         err << "Rendering a " << prm.image_width << "x" << prm.image_height << " image with " << prm.samples_per_pixel << " samples per pixel ";
-        err << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows" : ", list scan") << ").\n";
+        err << "(" << kFpName << (prm.use_bvh ? ", acceleration grid where the scene allows; same bits as -b for spheres and fp64 meshes" : ", list scan") << ").\n";
         err << "num_hittables = " << (counts[1] + counts[2] + counts[3]) << "\n";
 
         double seconds = 0, samples = 0, bytes_algorithmic = 0;
         unsigned long long segments = 0, prim_tests = 0;
-        int blocks = 0, accel_cells = 0;
+        int blocks = 0, accel_cells = 0, accel_exact = 1;
         std::string how;
         if (group_size > 1) {
             err << "HIP Devices:";
@@ -287,7 +292,7 @@ struct Worker {
             rc = rrtx_group_render(group, fb->data(), &gs);
             if (rc) die(rc, err.str());
             seconds = gs.device_ms / 1000.0, samples = (double)gs.samples, bytes_algorithmic = (double)gs.bytes_algorithmic;
-            segments = gs.segments, prim_tests = gs.prim_tests, accel_cells = gs.accel_cells;
+            segments = gs.segments, prim_tests = gs.prim_tests, accel_cells = gs.accel_cells, accel_exact = gs.accel_exact;
             std::ostringstream h;
             h << group_size << " devices: slowest render " << gs.render_ms / 1000.0 << " s, gather " << gs.gather_ms / 1000.0 << " s (" << gs.gathered_bytes << " bytes" << (gs.rccl ? ", RCCL" : ", copies") << "),";
             how = h.str();
@@ -299,7 +304,7 @@ struct Worker {
             rc = rrtx_render(ctx, fb->data(), &st);
             if (rc) die(rc, err.str());
             seconds = st.kernel_ms / 1000.0, samples = (double)st.samples, bytes_algorithmic = (double)st.bytes_algorithmic;
-            segments = st.segments, prim_tests = st.prim_tests, blocks = st.grid_blocks, accel_cells = st.accel_cells;
+            segments = st.segments, prim_tests = st.prim_tests, blocks = st.grid_blocks, accel_cells = st.accel_cells, accel_exact = st.accel_exact;
         }
         err << "took " << seconds << " seconds.\n";
         char hostname[HOST_NAME_MAX + 1];
@@ -312,7 +317,8 @@ struct Worker {
             << blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
         if (seconds > 0)
             err << "rate," << samples / seconds / 1e6 << " Msamples/s," << how << segments << " segments," << prim_tests << " primitive tests," << bytes_algorithmic / seconds / 1e9
-                << " GB/s algorithmic," << (accel_cells ? "grid of " + std::to_string(accel_cells) + " cells" : std::string("list scan")) << "\n";
+                << " GB/s algorithmic," << (accel_cells ? "grid of " + std::to_string(accel_cells) + " cells" : std::string("list scan"))
+                << (accel_exact ? "" : ",approximate rule (fp32 triangles gridded under an empirical inflation: -X or -b for the list scan's bits)") << "\n";
         rrtx_scene_free(scene);
         log(err.str());
 
@@ -405,6 +411,7 @@ int main(int argc, char *argv[])
         case 'T': prm.tile_rows = atoi(next()); break;
         case 'G': n_gpus = atoi(next()); break;
         case 'E': rehearse = true; break;
+        case 'X': prm.flags |= RRTX_FLAG_EXACT_ACCEL; break;
         default: usage(argv[i]);
         }
     }

@@ -425,7 +425,19 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 256);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_counters, 256);
     if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 256);
-    if (e == hipSuccess && c->use_partial) e = hipMalloc(&c->d_partial, (size_t)c->total_tasks * 3 * c->fsize + 64);
+    if (e == hipSuccess && c->use_partial) {
+        // (footprint: one vec3 per work item - 0.73 GB for 1200x800 spp 500, 6.3 GB fp32 / 12.5 GB fp64 for 3840x2160 spp 1000 at
+        // 16 samples per item; several contexts on one device each hold their own)
+        const size_t bytes = (size_t)c->total_tasks * 3 * c->fsize + 64;
+        e = hipMalloc(&c->d_partial, bytes);
+        if (e != hipSuccess) {
+            char buf[384];
+            snprintf(buf, sizeof buf, "rrtx_create: cannot allocate %.2f GB for the per-work-item sums (%u work items of %d samples): HIP error = %u (%s); raise sample_chunk (`rrt -C`) to shrink it",
+                     (double)bytes / 1e9, (unsigned)c->total_tasks, c->chunk, (unsigned)e, hipGetErrorString(e));
+            rrtx_destroy(c);
+            return fail(RRTX_E_DEVICE, buf);
+        }
+    }
 #ifdef RRTX_DIAG
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_diag, (size_t)131072 * 64);
     if (e == hipSuccess) e = hipMemset(c->d_diag, 0, (size_t)131072 * 64);
@@ -490,9 +502,11 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         return fail(RRTX_E_INVALID, "rrtx_set_scene: count without table");
     if ((int64_t)s->num_spheres + s->num_moving_spheres + s->num_triangles > (1 << 28)) return fail(RRTX_E_INVALID, "rrtx_set_scene: too many primitives");
     // (the tables of the previous scene are overwritten in place: nothing may still be rendering from them, on whatever stream
-    // the caller launched - rrtx_render_device takes any)
+    // the caller launched - rrtx_render_device takes any and records a stop event on it; waiting for those events and for the
+    // context's own stream instead of the whole device leaves other contexts and a host application's streams alone)
     RRTX_HIP(hipSetDevice(c->device));
-    RRTX_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < c->ev_pending; ++i) RRTX_HIP(hipEventSynchronize(c->ev_stop[i]));
+    RRTX_HIP(hipStreamSynchronize(c->stream));
     int rc = c->p.fp64 ? upload_scene<double>(c, s) : upload_scene<float>(c, s);
     if (rc) return rc;
     // persistent grid: fill the chip once with the kernel variant this scene selects; never more

@@ -123,6 +123,7 @@ struct rrtx_group {
     std::vector<uint32_t> row_off; // rows before member r in the gathered buffer
     std::vector<hipEvent_t> ev_done;
     const Rccl *rccl = nullptr;
+    int rccl_version = 0; // ncclGetVersion (0: rehearsal, no communicator)
     std::vector<ncclComm_t> comms;
     void *d_gathered = nullptr, *d_frame = nullptr; // on devs[0]
     hipEvent_t ev_begin = nullptr, ev_frame = nullptr;
@@ -132,9 +133,8 @@ struct rrtx_group {
 
 namespace {
 
-int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, void *fb)
+int group_render_enqueue_and_wait(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, void *fb)
 {
-    if (!g->have_scene) return set_error(RRTX_E_NO_SCENE, "rrtx_group_render: no scene set");
     const auto t0 = std::chrono::steady_clock::now();
     const size_t row_bytes = (size_t)g->p.image_width * 3 * g->fsize;
     hipStream_t s0 = (hipStream_t)rrtx_stream(g->ctx[0]);
@@ -196,6 +196,9 @@ int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, 
     rrtx_group_stats st;
     memset(&st, 0, sizeof st);
     st.n_devices = g->n, st.rccl = g->rehearsal ? 0 : 1;
+    st.accel_exact = 1;
+    st.rccl_version = g->rccl_version, st.rccl_comms = (int32_t)g->comms.size();
+    for (int r = 0; r < g->n && r < 16; ++r) st.devices[r] = g->devs[r];
     for (int r = 0; r < g->n; ++r) {
         rrtx_stats ms;
         int rc = rrtx_collect(g->ctx[r], &ms);
@@ -205,6 +208,7 @@ int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, 
         st.samples += ms.samples, st.segments += ms.segments, st.prim_tests += ms.prim_tests, st.bytes_algorithmic += ms.bytes_algorithmic;
         st.gathered_bytes += (uint64_t)g->rows[r] * row_bytes;
         st.sample_chunk = ms.sample_chunk, st.accel_cells = ms.accel_cells;
+        if (!ms.accel_exact) st.accel_exact = 0;
     }
     GRP_HIP(hipSetDevice(g->devs[0]));
     float ms = 0.f;
@@ -214,6 +218,26 @@ int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, 
     st.wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (stats) *stats = st;
     return RRTX_OK;
+}
+
+// A failure anywhere after the first shard render was enqueued must not leave the members with work in flight and
+// undrained event slots (they would fail, or time garbage, on their next render): wait for every member's stream and
+// collect its events, keeping the first failure's message.
+int group_render_device(rrtx_group *g, rrtx_group_stats *stats, bool copy_back, void *fb)
+{
+    if (!g->have_scene) return set_error(RRTX_E_NO_SCENE, "rrtx_group_render: no scene set");
+    const int rc = group_render_enqueue_and_wait(g, stats, copy_back, fb);
+    if (rc != RRTX_OK) {
+        const std::string keep = rrtx_last_error();
+        for (int r = 0; r < g->n; ++r) {
+            (void)hipSetDevice(g->devs[r]);
+            (void)hipStreamSynchronize((hipStream_t)rrtx_stream(g->ctx[r]));
+            (void)rrtx_collect(g->ctx[r], nullptr);
+        }
+        (void)hipSetDevice(g->devs[0]);
+        set_error(rc, keep);
+    }
+    return rc;
 }
 
 } // namespace
@@ -307,8 +331,9 @@ int rrtx_group_create(const rrtx_params *params, int n_devices, const int32_t *d
         g->comms.assign(n_devices, nullptr);
         // RCCL greets on STDOUT ("RCCL version : ..."), and stdout is where `rrt` prints its PPM (main.cpp:142): while the
         // communicators are built, file descriptor 1 points at stderr
+        // (process-wide, see RRTX_GROUP_KEEP_STDOUT in rrtx.h: a caller that writes to stdout from other threads diverts it itself)
         fflush(stdout);
-        const int saved_stdout = ::dup(1);
+        const int saved_stdout = (flags & RRTX_GROUP_KEEP_STDOUT) ? -1 : ::dup(1);
         if (saved_stdout >= 0) (void)::dup2(2, 1);
         ncclResult_t r = g->rccl->CommInitAll(g->comms.data(), n_devices, g->devs.data());
         fflush(stdout);
@@ -317,6 +342,8 @@ int rrtx_group_create(const rrtx_params *params, int n_devices, const int32_t *d
             ::close(saved_stdout);
         }
         if (r != ncclSuccess) return bail(set_error(RRTX_E_DEVICE, std::string("rrtx_group_create: ncclCommInitAll: ") + g->rccl->GetErrorString(r)));
+        int v = 0;
+        if (g->rccl->GetVersion(&v) == ncclSuccess) g->rccl_version = v;
     }
     *out = g;
     return RRTX_OK;

@@ -33,7 +33,8 @@ def test_struct_sizes_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "rrtx.h"\nint main(void){printf("%zu %zu %zu %zu ", sizeof(rrtx_params), sizeof(rrtx_stats), sizeof(rrtx_scene_desc), sizeof(rrtx_devinfo));'
                    'printf("%zu %zu %zu %zu %zu ", sizeof(rrtx_camera_f32), sizeof(rrtx_material_f32), sizeof(rrtx_sphere_f32), sizeof(rrtx_moving_sphere_f32), sizeof(rrtx_triangle_f32));'
-                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(rrtx_camera_f64), sizeof(rrtx_material_f64), sizeof(rrtx_sphere_f64), sizeof(rrtx_moving_sphere_f64), sizeof(rrtx_triangle_f64));return 0;}\n')
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(rrtx_camera_f64), sizeof(rrtx_material_f64), sizeof(rrtx_sphere_f64), sizeof(rrtx_moving_sphere_f64), sizeof(rrtx_triangle_f64));'
+                   'printf("%zu\\n", sizeof(rrtx_group_stats));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])  # the header is plain C
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
@@ -41,6 +42,7 @@ def test_struct_sizes_match_the_header(tmp_path):
     # reference layouts (measured on the compiled reference)
     assert got[4:9] == [96, 32, 32, 56, 40]
     assert got[9:14] == [192, 40, 40, 80, 80]
+    assert got[14] == C.sizeof(_lib.GroupStats)
     import rrt_amd.render as rr
 
     for fp64, sizes in ((False, got[4:9]), (True, got[9:14])):

@@ -13,14 +13,26 @@ the oracle BIT FOR BIT (zero tolerance, same summation shape), the accelerated c
 CLI's default) must give the same frame, and the 8-way row-tile decomposition - executed shard after shard on
 the one GPU of the test box - must assemble to the unsharded frame.  Oracle time: 2 - 5 s per row.
 """
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
-from _oracle import Oracle, have_reference, scene_path
+from _oracle import GOLDEN, Oracle, have_reference, scene_path
 
 pytestmark = pytest.mark.gpu
 
 TEST1, FINAL = scene_path("test1"), scene_path("final")
+
+
+def _row_hashes(fb, rows):
+    """blake2b-64 of each row's raw radiance bytes: what tools/make_rowhash.py stored for the ORACLE's frame"""
+    return np.array([int.from_bytes(hashlib.blake2b(np.ascontiguousarray(fb[j]).tobytes(), digest_size=8).digest(), "little") for j in rows], dtype=np.uint64)
+
+
+ROWHASH_META = json.load(open(os.path.join(GOLDEN, "rowhash_meta.json")))
 
 
 def _render(gpu, path, w, h, spp, fp64=False, **kw):
@@ -91,6 +103,15 @@ def test_config3_and_4_final_1200x800_spp500(gpu, fp64):
     assert (2.30 < seg < 2.34) if fp64 else (2.51 < seg < 2.54), seg  # 2.318 (fp64) / 2.525 (fp32)
     assert st["prim_tests"] == st["segments"] * 488
     assert np.isfinite(fb).all() and (fb >= 0).all()
+    # the WHOLE frame against the oracle: every one of the 800 rows by its hash (tools/make_rowhash.py rendered the oracle's
+    # frame - 5.9e11 primitive tests - in the container and committed one 64-bit hash per row), and the segment count
+    meta = ROWHASH_META["c4" if fp64 else "c3"]
+    assert (meta["w"], meta["h"], meta["spp"], meta["chunk"], meta["rows"]) == (w, h, spp, st["sample_chunk"], h)
+    want = np.load(os.path.join(GOLDEN, "c4_rowhash_f64.npy" if fp64 else "c3_rowhash_f32.npy"))
+    got = _row_hashes(fb, range(h))
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    assert st["segments"] == meta["segments"]
+    # ... and three rows bit by bit, live (a hash can say THAT a row differs, this says where)
     o = Oracle(FINAL, w, h, fp64)
     for j in (2, 388, 799):  # ground, the sphere layer, sky
         fo, _ = o.render(spp, 50, 1984, order=1, chunk=8, rows=(j, j + 1))
@@ -115,6 +136,11 @@ def test_config5_final_3840x2160_spp1000_as_8_shards(gpu):
     assert w * h * cpp < 2 ** 31 and st["samples"] == w * h * spp
     assert 2.47 < st["segments"] / st["samples"] < 2.52  # (16:9 here against 3:2 in C3: more sky in the frame, 2.4935)
     assert np.isfinite(full).all() and (full >= 0).all()
+    # 64 rows from the ground to the sky against the oracle's hashes (tools/make_rowhash.py), one row live
+    meta = ROWHASH_META["c5"]
+    assert (meta["w"], meta["h"], meta["spp"], meta["chunk"]) == (w, h, spp, chunk)
+    fx = np.load(os.path.join(GOLDEN, "c5_rowhash_f32.npz"))
+    assert len(fx["rows"]) == 64 and np.array_equal(_row_hashes(full, fx["rows"]), fx["hash"])
     o = Oracle(FINAL, w, h, False)
     j = 1049  # through the three large spheres
     fo, _ = o.render(spp, 50, 1984, order=1, chunk=chunk, rows=(j, j + 1))

@@ -161,5 +161,11 @@ def test_bench_line_of_a_two_rank_run(gpu):
     assert j["kernel_only_ms_per_step"] > 0 and j["gather_ms_per_step"] >= 0
     assert j["roofline"]["bound"] == "valu_issue" and 0 < j["roofline"]["frac"] <= 1 and "logical_hbm" in j["roofline"]
     assert "cpu_baseline" not in j  # rank 0 at N = 1 only
+    rc = j["config"]["rccl"]  # what the process group saw: the driver is the only one who can run N > 1 on real devices
+    assert rc["ranks"] == 2 and rc["backend"] == "gloo" and len(rc["devices"]) == 2 and [d["rank"] for d in rc["devices"]] == [0, 1]
+    assert all(d["name"] and d["ordinal"] == 0 for d in rc["devices"]) and rc["distinct_devices"] == 1  # (a rehearsal: both ranks on this box's one GPU)
+    c3 = j["strong_c3"]  # north_star's 7.5 x is stated on configuration 3: split the same way by the same job, next to C3 whole on rank 0's GPU
+    assert "1200x800" in c3["workload"] and c3["ms_per_step"] >= c3["kernel_only_ms_per_step"] > 0 and c3["one_gpu_ms_per_step"] > 0 and c3["speedup_vs_one_gpu"] > 0
+    assert abs(c3["value"] - 1200 * 800 * 24 / (c3["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * c3["value"]
     one = j["one_gpu_same_workload"]  # the same frame on rank 0's GPU alone, inside the same job
     assert "error" not in one and one["ms_per_step"] > 0 and abs(one["value"] - 3840 * 2160 * 24 / (one["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * one["value"]

@@ -68,8 +68,14 @@ def test_every_device_of_the_box(gpu):
     g = gpu.RrtGroup(n, w, h, spp, 50, use_bvh=True, tile_rows=4)
     assert len(g) == n
     fb = g.render(gpu.Scene(FINAL, w, h))
-    assert g.stats["rccl"] == 1 and g.stats["n_devices"] == n and g.stats["accel_cells"] > 0
+    st = g.stats
+    # (on a box with one GPU this is N = 1; on the first lease with two or more it pins the multi-device exchange - ncclSend /
+    # ncclRecv between distinct ranks, cross-device stream order - against the ORACLE without new code)
+    assert st["rccl"] == 1 and st["n_devices"] == n == gpu.device_count() and st["accel_cells"] > 0
+    assert st["rccl_comms"] == n and st["rccl_version"] > 0 and st["devices"] == list(range(n)) and st["accel_exact"] == 1
     assert np.array_equal(fb, want)
+    fo, so = Oracle(FINAL, w, h, False).render(spp, 50, 1984, order=1, chunk=spp)
+    assert np.array_equal(fb, fo) and st["segments"] == so["segments"]
     g.close()
 
 

@@ -123,3 +123,64 @@ def test_fp32_plane_mesh_at_grazing_angles(gpu, tmp_path, cam):
     assert ((scan != grid).any(axis=2)).mean() <= 1e-4
     _, sv = _render(gpu, f, w, h, 2, use_bvh=True, flags=VERIFY)
     assert sv["list_mismatches"] <= 1e-5 * sv["segments"], (sv["list_mismatches"], sv["segments"])
+
+
+def _random_mesh_scene(path, seed):
+    """A mesh that is NOT a UV sphere: a bumpy height field (ridges, creases, slivers where the grid is sheared), a cloud of
+    free triangles of random size and orientation (1e-2 ... 0.5 units, some nearly degenerate), glass and metal among the
+    materials, a camera that looks along the terrain - so that camera rays and bounces skim many triangle planes."""
+    rng = np.random.default_rng(seed)
+    cam = "camera %r %r %r  0 0.2 0  0 1 0  %r %r %r" % (float(rng.uniform(5, 9)), float(rng.uniform(0.4, 2.5)), float(rng.uniform(-6, 6)), float(rng.uniform(25, 50)),
+                                                          float(rng.choice([0.0, 0.05])), float(rng.uniform(5, 10)))
+    lines = [cam, "material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 0.1", "material g dielectric 1.5", "material r lambertian 0.2 0.7 0.3"]
+    for k in range(40):
+        lines.append("sphere %r 0.3 %r 0.15 %s" % (float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)), "amg"[k % 3]))
+    n = int(rng.integers(40, 70))
+    xs = np.linspace(-6, 6, n + 1) + rng.uniform(-0.03, 0.03, n + 1)
+    zs = np.linspace(-6, 6, n + 1) + rng.uniform(-0.03, 0.03, n + 1)
+    fx, fz = rng.uniform(0.5, 2.0, 2)
+    hgt = 0.15 * np.sin(fx * xs[:, None]) * np.cos(fz * zs[None, :]) + 0.02 * rng.standard_normal((n + 1, n + 1)) * (rng.uniform(0, 1, (n + 1, n + 1)) < 0.3)
+    shear = rng.uniform(-0.15, 0.15)  # sheared columns: slivers
+    lines.append("obj_beg %d %d" % ((n + 1) ** 2, 2 * n * n))
+    lines += ["obj_vtx %r %r %r" % (float(xs[i] + shear * (j % 2)), float(hgt[i, j]), float(zs[j])) for i in range(n + 1) for j in range(n + 1)]
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = i * (n + 1) + j, i * (n + 1) + j + 1, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1
+            lines += ["obj_tri %d %d %d" % (a, b, c), "obj_tri %d %d %d" % (b, d, c)]
+    lines += ["obj_end", "obj 0 r"]
+    m = int(rng.integers(400, 900))  # the cloud
+    lines.append("obj_beg %d %d" % (3 * m, m))
+    for _ in range(m):
+        p = rng.uniform([-5, 0.3, -5], [5, 2.5, 5])
+        size = float(np.exp(rng.uniform(np.log(0.01), np.log(0.5))))
+        e1, e2 = rng.standard_normal(3), rng.standard_normal(3)
+        e1 *= size / np.linalg.norm(e1)
+        e2 = e2 * size / np.linalg.norm(e2) if rng.random() > 0.2 else e1 * rng.uniform(0.5, 1.5) + 1e-3 * size * e2  # a fifth: slivers
+        for v in (p, p + e1, p + e2):
+            lines.append("obj_vtx %r %r %r" % tuple(float(x) for x in v))
+    lines += ["obj_tri %d %d %d" % (3 * k, 3 * k + 1, 3 * k + 2) for k in range(m)]
+    lines += ["obj_end", "obj 1 m", "obj 1 g t 0.3 0.1 -0.2 r 30 0 1 0", "obj 1 a s 1.5 1.0 1.5 t 0 0.4 0"]
+    path.write_text("\n".join(lines) + "\n")
+    return str(path), 2 * n * n + 3 * m
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_fp32_random_meshes_through_the_verify_build(gpu, tmp_path, seed):
+    """The approximate rule on meshes built to strain it (tests/test_tri_inflation.py has the CPU search and the stated safe
+    set): the VERIFY build re-scans EVERY walked segment sequentially and counts the disagreements; the stated bound is 1e-5 of
+    the segments (`include/rrtx.h`, RRTX_FLAG_EXACT_ACCEL), and the frames of the two modes may differ in <= 1e-4 of the pixels."""
+    f, n_tri = _random_mesh_scene(tmp_path / "rmesh.txt", seed)
+    assert n_tri > 4000
+    w, h, spp = 240, 160, 4
+    scan, s0 = _render(gpu, f, w, h, spp)
+    grid, s1 = _render(gpu, f, w, h, spp, use_bvh=True)
+    assert s1["accel_cells"] > 0 and s1["accel_exact"] == 0
+    assert ((scan != grid).any(axis=2)).mean() <= 1e-4
+    _, sv = _render(gpu, f, w, h, spp, use_bvh=True, flags=VERIFY)
+    assert sv["segments"] > 200000
+    assert sv["list_mismatches"] <= 1e-5 * sv["segments"], (sv["list_mismatches"], sv["segments"])
+    exact, s2 = _render(gpu, f, w, h, spp, use_bvh=True, flags=EXACT_ACCEL)
+    assert s2["accel_exact"] == 1 and np.array_equal(exact, scan)
+    o = Oracle(f, w, h, False)  # ... and the list scan's rows are the oracle's
+    fo, _ = o.render(spp, 50, 1984, order=1, chunk=spp, rows=(40, 41))
+    assert np.array_equal(scan[40], fo[40])

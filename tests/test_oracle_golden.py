@@ -119,3 +119,27 @@ def test_scene_errors_use_reference_exit_codes(tmp_path):
     assert code(cam + mat + "obj_beg 1 1\nobj_vtx 0 0 0\nobj_end\n") == 1
     with pytest.raises(ValueError):
         Oracle(str(tmp_path / "missing.txt"), 8, 8)
+
+
+@pytest.mark.parametrize("cfg", ["c3", "c4", "c5"])
+def test_rowhash_fixtures_are_the_oracles(cfg):
+    """tests/golden/c3_rowhash_f32.npy, c4_rowhash_f64.npy, c5_rowhash_f32.npz (tools/make_rowhash.py: one 64-bit hash per row of
+    the oracle's frame at the BASELINE configuration's full size) - spot-checked here against a live oracle render of a few of
+    those rows, so that the fixtures the GPU tier compares every row with cannot drift from the oracle that made them."""
+    import hashlib
+    import json
+
+    meta = json.load(open(os.path.join(GOLDEN, "rowhash_meta.json")))[cfg]
+    w, h, spp, chunk, fp64 = meta["w"], meta["h"], meta["spp"], meta["chunk"], meta["fp64"]
+    if cfg == "c5":
+        fx = np.load(os.path.join(GOLDEN, "c5_rowhash_f32.npz"))
+        rows, want = [int(fx["rows"][40])], {int(r): int(v) for r, v in zip(fx["rows"], fx["hash"])}
+    else:
+        table = np.load(os.path.join(GOLDEN, "c3_rowhash_f32.npy" if cfg == "c3" else "c4_rowhash_f64.npy"))
+        assert table.shape == (h,) and len(set(table.tolist())) == h  # (every row of this scene differs from every other)
+        rows, want = [2, 431], {j: int(table[j]) for j in range(h)}
+    o = Oracle(scene_path("final"), w, h, fp64)
+    for j in rows:
+        fb, _ = o.render(spp, 50, 1984, order=1, chunk=chunk, rows=(j, j + 1))
+        got = int.from_bytes(hashlib.blake2b(np.ascontiguousarray(fb[j]).tobytes(), digest_size=8).digest(), "little")
+        assert got == want[j], (cfg, j)
