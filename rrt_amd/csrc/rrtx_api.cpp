@@ -641,6 +641,12 @@ extern "C" int rrtx_resume_diag(rrtx_ctx *c, unsigned long long out[8]) // devel
 }
 #endif
 #ifdef RRTX_SECTION_DIAG
+extern "C" int rrtx_dense_diag(rrtx_ctx *c, unsigned long long out[8]) // developer builds: what the dense pairing of the accelerated variants was fed (rrtx_kernels.hip, dense_dbg)
+{
+    RRTX_HIP(hipDeviceSynchronize());
+    RRTX_HIP(hipMemcpy(out, c->d_counters + 8, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int rrtx_section_diag(rrtx_ctx *c, unsigned long long out[8]) // developer builds: a wave's clock cycles per section of the render loop, summed over the waves
 {
     RRTX_HIP(hipDeviceSynchronize());

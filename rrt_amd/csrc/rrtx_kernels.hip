@@ -24,6 +24,7 @@
 
 #include "rrtx_device.h"
 #include "rrtx_path.h" // the arithmetic of the path (shared with the host-side check)
+#include "rrtx_wave.h" // wave64 prefix scans (DPP)
 
 namespace rrtx {
 
@@ -204,6 +205,115 @@ template <typename F, bool SO = false, typename HotTab> __device__ __forceinline
     }
     return hb;
 }
+
+// The reference's sequential scan (hittable_list.h:95-117) by one lane: every primitive in list order with the exact test
+// and the running closest_so_far.  What the accelerated variants fall back to for the rays the unordered rule is not
+// proven for (non-finite or absurd components: practically never), and what the VERIFY builds compare against.
+template <typename F> __device__ __forceinline__ HitInfo<F> sequential_closest_hit(const KernelParams<F> &P, const Path<F> &path, F a, F t_min)
+{
+    HitInfo<F> full = {Limits<F>::inf(), -1};
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    for (int q = 0; q < P.n_sph; ++q) {
+        const SphereHot<F> gq = P.sph_hot[q];
+        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
+    }
+    for (int q = 0; q < P.n_msph; ++q) {
+        const MovingSphereRec<F> ms = P.msph[q];
+        const V3<F> cen = msphere_center<F>(ms, path.tm);
+        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
+    }
+    for (int q = 0; q < P.n_tri; ++q) {
+        F tt;
+        if (triangle_test<F, true>(P.tri[q], path, t_min, full.t, tt)) {
+            full.t = tt;
+            full.idx = tri_base + q;
+        }
+    }
+    return full;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense (ray, entry) pairs (accelerated variants).  In the grid walk every lane used to run its own loops - over the cells of
+// its slice, over each cell's entries - and the wave paid for the LONGEST of them: 2.8 trips of the test loop per cell for 1.9
+// entries per lane and cell, with 20 of 64 lanes left in the average trip (35 % lane utilisation over the whole kernel, round 2).
+// Here every lane only LISTS what it wants tested this iteration - the entries of the next cells of its walk
+// (accel_walk_prepare: up to four (first, count) ranges of cell_prims), or, for a fresh camera ray, its pixel's candidate list
+// (+ every moving sphere and triangle, as the LIST passes of the list-scan kernel test them) - and the wave then shares all
+// those (ray, entry) pairs out evenly: pair p = base + lane of a trip belongs to the lane whose range [off, off + n) of the
+// prefix sum holds p (found with one mark per owner in LDS and a prefix maximum), its ray comes across with ds_bpermute, and
+// the lane evaluates the exact test's REJECTION part for it - the discriminant of sphere.h:35-41, the a / u / v cuts of
+// triangle.h:38-56 - with the owner's operands in the owner's arithmetic.  Pairs that are not rejected are pushed onto the
+// owner's candidate list in LDS (an atomic slot counter per owner), and each owner afterwards runs the full exact test on its
+// few candidates with consider()'s order-independent rule - the answer of the sequential scan (rrtx_path.h).  More than CAP
+// candidates for one owner: that lane tests its own entries itself.
+// All 64 lanes call this, converged.  marks / cnts: 64 dwords of LDS each, this wave's; cand: CAP x 64 dwords, slot s of lane
+// l at cand[s * 64 + l].
+// ---------------------------------------------------------------------------------------------
+template <typename F, bool SO, int CAP, typename HotTab, typename PrimTab>
+__device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const HotTab &hot, const PrimTab &cell_prims, const uint16_t *plist, const Path<F> &path, F a, const WalkRanges &R,
+                                                  bool is_list, uint32_t n_own, int lane, uint32_t *marks, uint32_t *cnts, uint32_t *cand)
+{
+    const uint32_t incl = wave_scan_add(n_own), off = incl - n_own;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    cnts[lane] = 0u;
+    const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
+    const uint32_t off_and_kind = off | (is_list ? 0x80000000u : 0u);
+    for (uint32_t base = 0; base < total; base += 64u) {
+        // whose pair is base + lane?  Every owner marks the first slot of its range inside this window; a prefix maximum
+        // carries the mark to the slots behind it (ranges are disjoint and in lane order)
+        marks[lane] = 0u;
+        if (n_own != 0u && off < base + 64u && off + n_own > base) marks[off > base ? off - base : 0u] = (uint32_t)lane + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (LDS operations of a wave execute in order: this only keeps the compiler from moving them)
+        const uint32_t m = wave_scan_max(marks[lane]);
+        const uint32_t p = base + (uint32_t)lane;
+        const bool live = p < total;
+        const int owner = live ? (int)m - 1 : lane;
+        const uint32_t o_ok = (uint32_t)__shfl((int)off_and_kind, owner), o_cnt = (uint32_t)__shfl((int)R.cnt, owner);
+        const uint32_t o_b0 = (uint32_t)__shfl((int)R.beg0, owner), o_b1 = (uint32_t)__shfl((int)R.beg1, owner), o_b2 = (uint32_t)__shfl((int)R.beg2, owner), o_b3 = (uint32_t)__shfl((int)R.beg3, owner);
+        Path<F> rp;
+        rp.o = mk<F>(__shfl(path.o.x, owner), __shfl(path.o.y, owner), __shfl(path.o.z, owner));
+        rp.d = mk<F>(__shfl(path.d.x, owner), __shfl(path.d.y, owner), __shfl(path.d.z, owner));
+        rp.tm = SO ? (F)0 : __shfl(path.tm, owner);
+        rp.atten = mk<F>(0, 0, 0), rp.depth = 0;
+        const F ra = __shfl(a, owner);
+        if (live) {
+            const uint32_t j = p - (o_ok & 0x7FFFFFFFu);
+            const uint32_t e = walk_range_entry(o_b0, o_b1, o_b2, o_b3, o_cnt, j);
+            int idx;
+            if (!(o_ok & 0x80000000u))
+                idx = (int)cell_prims[e];
+            else if (j < (o_cnt & 255u))
+                idx = (int)plist[(size_t)o_b0 * kPlistStride + 1u + j]; // range 0 of a camera ray: its pixel's list (beg0 = the pixel)
+            else
+                idx = (int)e; // ranges 1, 2 of a camera ray: every moving sphere, every triangle
+            bool keep;
+            if (SO || idx < msph_base) {
+                const SphereHot<F> g = hot[idx];
+                const F ocx = rp.o.x - g.cx, ocy = rp.o.y - g.cy, ocz = rp.o.z - g.cz; // sphere.h:35-40
+                const F half_b = ocx * rp.d.x + ocy * rp.d.y + ocz * rp.d.z;
+                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.r2;
+                keep = !(half_b * half_b - ra * c < 0);
+            }
+            else if (idx < tri_base) {
+                const MovingSphereRec<F> ms = P.msph[idx - msph_base];
+                const V3<F> cen = msphere_center<F>(ms, rp.tm);
+                const F ocx = rp.o.x - cen.x, ocy = rp.o.y - cen.y, ocz = rp.o.z - cen.z;
+                const F half_b = ocx * rp.d.x + ocy * rp.d.y + ocz * rp.d.z;
+                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - ms.r2;
+                keep = !(half_b * half_b - ra * c < 0);
+            }
+            else {
+                F dummy;
+                keep = triangle_test<F, false>(P.tri[idx - tri_base], rp, (F)0, (F)0, dummy);
+            }
+            if (keep) {
+                const uint32_t slot = atomicAdd(&cnts[owner], 1u); // ds_add_rtn_u32
+                if (slot < (uint32_t)CAP) cand[slot * 64u + (uint32_t)owner] = (uint32_t)idx;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
 template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
@@ -211,6 +321,15 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     // thousand and rather keep the LDS for a sixth block per CU
     constexpr int kCap = ACCEL != 0 ? 8 : kCandCap;
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCap][64];
+    // accelerated variants: the dense (ray, entry) pairing's owner marks and candidate counters (dense_candidates)
+    // Measured (round 3): the dense pairing wins where a test is dear and a lane's loops are long - scenes with triangles or
+    // moving spheres: 27 072 triangles 600x400 spp 16: 20.7 -> 15.7 ms (fp64 21.5 -> 15.6), frames identical - and loses where the
+    // walk was cheap to begin with: final.txt (488 spheres, tables in LDS) 37.6 -> 46.5 ms, 40 000 spheres 8.5 -> 9.4 ms - there a
+    // lane's listing of its cells costs more than the per-lane walk it replaces (EXPERIMENTS.md).  So: scenes of spheres alone keep
+    // the per-lane walk, everything else is paired densely.
+    constexpr bool kDensePairs = ACCEL != 0 && !SO;
+    constexpr int kDenseLds = kDensePairs ? 64 : 1;
+    __shared__ uint32_t dense_marks[kWavesPerBlock][kDenseLds], dense_cnts[kWavesPerBlock][kDenseLds];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     typedef typename ScanType<F, FILTER>::type ST; // precision of the scan's records: the filter is fp32 for every F
     SphereHot<ST> *const sph_lds = (SphereHot<ST> *)dyn_lds;
@@ -284,6 +403,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
 #endif
 
 #ifdef RRTX_SECTION_DIAG // developer builds: clock cycles of a wave per section of the loop -> counters[16 + k]
+    unsigned long long dense_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long sec_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sec_t = __builtin_amdgcn_s_memtime();
     int sec_cur = 0;
 #define RRTX_SEC(k)                                                                                                                        \
@@ -486,6 +606,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // at most `list_passes` such passes (sky hits regenerate, so a lane may need several) a SCAN pass
         // runs the 488-sphere scan for every lane, by then almost all on secondary rays.  Every segment
         // is still intersected exactly once with the exact test in primitive order: same image.
+        // (kDensePairs: which accelerated variants share the (ray, entry) pairs of a wave out over its lanes - see the other branch)
+        if constexpr (!kDensePairs) {
         RRTX_SEC(2); // camera-ray lists (LIST passes) / walk
         const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0 && !(ACCEL != 0 && in_walk);
         const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
@@ -768,6 +890,145 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     need_ray = true;
             }
         }
+        } // !kDensePairs
+        else {
+            // ---------------- accelerated closest hit: the wave's (ray, entry) pairs tested densely ------------------
+            // Every lane lists what it wants tested in this iteration: a fresh camera ray its pixel's candidate list (and every
+            // moving sphere and triangle), any other segment the entries of the next cells of its walk through the grid
+            // (accel_walk_prepare: the always-list and the box clip of a new segment, then up to `slice` cells of the DDA); the 64
+            // lanes then test all those pairs together (dense_candidates), every owner finishes its few candidates with the
+            // exact test and consider()'s order-independent rule, and walks whose slice settled the closest hit go on to shade.
+            // There are no LIST and SCAN passes here: camera rays and walks are served by the same trips.
+            RRTX_SEC(2);
+            bool done = false, resolved = false, need_scan = false;
+            V3<F> radiance = mk<F>(0, 0, 0);
+            const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
+            // (tables in LDS: slices of 4 cells; the grids that ask for more, large and mostly empty, live in HBM; the macro: experiments)
+            const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : (ACCEL == 2 ? 4 : C.grid.walk_slice);
+            WalkRanges R = {0u, 0u, 0u, 0u, 0u};
+            bool is_list = false, walking = false, ended = false;
+            F t_last = 0, slack_t = 0, a = 0;
+            if (alive && P.max_depth <= 0) // rrt.cu:47 loop body never runs
+                done = true;
+            else if (alive) {
+                a = vlen2<F>(path.d); // sphere.h:36
+                if (!in_walk) {
+                    n_segments += 1;
+                    best.t = Limits<F>::inf();
+                    best.idx = -1;
+                }
+                if (in_walk && walk_cell == kCoopDone) // a far ray the wave resolved at the top of this iteration: `best` is final
+                    resolved = true, in_walk = false;
+                else if (!in_walk && path.depth == 0 && plist_count != 0xFFFFu) {
+                    // a fresh camera ray with a list.  The unordered rule needs a sane ray (the scene is finite wherever a grid was built)
+                    const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
+                    if (a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big()) {
+                        is_list = true;
+                        R.beg0 = task_pixel<F>(C, task), R.cnt = plist_count;
+                        if (!SO) R.beg1 = (uint32_t)msph_base, R.beg2 = (uint32_t)tri_base, R.cnt |= ((uint32_t)n_msph << 8) | ((uint32_t)n_tri << 16); // (<= 64 of them where lists exist)
+                    }
+                    else
+                        need_scan = true;
+                }
+                else {
+                    int r;
+                    if (ACCEL == 2)
+                        r = accel_walk_prepare<F, SO>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended);
+                    else
+                        r = accel_walk_prepare<F, SO>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended);
+                    if (r == kWalkDone)
+                        resolved = true, in_walk = false;
+                    else if (r == kWalkNeedsScan)
+                        need_scan = true, in_walk = false;
+                    else if (r == kWalkFarScan)
+                        walk_cell = kCoopWait, in_walk = true; // (waits, as a walk in progress, for the next top of the loop)
+                    else
+                        walking = true;
+                }
+            }
+            // ---- all 64 lanes: the pairs of the wave
+            RRTX_SEC(7);
+            const uint32_t n_own = walk_range_total(R.cnt);
+            if (ACCEL == 2)
+                dense_candidates<F, SO, kCap>(P, hot_lds, cell_prims_lds, C.plist, path, a, R, is_list, n_own, lane, &dense_marks[wave][0], &dense_cnts[wave][0], &cand_lds[wave][0][0]);
+            else
+                dense_candidates<F, SO, kCap>(P, P.sph_hot, P.grid_cell_prims, C.plist, path, a, R, is_list, n_own, lane, &dense_marks[wave][0], &dense_cnts[wave][0], &cand_lds[wave][0][0]);
+            // ---- every owner: the exact test of its candidates, in any order
+            RRTX_SEC(3);
+#ifdef RRTX_SECTION_DIAG // developer builds: what the dense pairing is fed, per wave and iteration -> counters[8 + k]
+            {
+                const uint32_t c_dbg = n_own != 0u ? dense_cnts[wave][lane] : 0u;
+                uint32_t pairs_dbg = n_own, cmax_dbg = c_dbg, csum_dbg = c_dbg;
+                for (int off_dbg = 32; off_dbg >= 1; off_dbg >>= 1) {
+                    pairs_dbg += __shfl_xor(pairs_dbg, off_dbg), csum_dbg += __shfl_xor(csum_dbg, off_dbg);
+                    const uint32_t o_dbg = __shfl_xor(cmax_dbg, off_dbg);
+                    cmax_dbg = o_dbg > cmax_dbg ? o_dbg : cmax_dbg;
+                }
+                dense_dbg[0] += 1, dense_dbg[1] += (pairs_dbg + 63u) / 64u, dense_dbg[2] += pairs_dbg, dense_dbg[3] += csum_dbg, dense_dbg[4] += cmax_dbg;
+                dense_dbg[5] += (unsigned long long)__popcll(__ballot(c_dbg > (uint32_t)kCap)), dense_dbg[6] += (unsigned long long)__popcll(__ballot(walking)), dense_dbg[7] += (unsigned long long)__popcll(__ballot(is_list));
+            }
+#endif
+            if (n_own != 0u) {
+                PendingRoot<F> pend = {-1, 0, 0};
+                const uint32_t c = dense_cnts[wave][lane];
+                n_candidates += c;
+                auto exact = [&](int idx) {
+                    if (ACCEL == 2)
+                        test_primitive<F, SO>(P, hot_lds, idx, path, a, t_min, best, pend);
+                    else
+                        test_primitive<F, SO>(P, P.sph_hot, idx, path, a, t_min, best, pend);
+                };
+                if (c <= (uint32_t)kCap) {
+                    for (uint32_t k = 0; k < c; ++k) exact((int)my_cand[k * 64]);
+                }
+                else { // more candidates than slots (a ray through a pile of primitives): this lane goes through its own entries
+                    for (uint32_t j = 0; j < n_own; ++j) {
+                        const uint32_t e = walk_range_entry(R.beg0, R.beg1, R.beg2, R.beg3, R.cnt, j);
+                        int idx;
+                        if (!is_list)
+                            idx = ACCEL == 2 ? (int)cell_prims_lds[e] : (int)P.grid_cell_prims[e];
+                        else if (j < (R.cnt & 255u))
+                            idx = (int)C.plist[(size_t)R.beg0 * kPlistStride + 1u + j];
+                        else
+                            idx = (int)e;
+                        exact(idx);
+                    }
+                }
+                resolve_pending<F>(pend, a, t_min, SO ? kNoTriangles : tri_base, best);
+            }
+            RRTX_SEC(4);
+            if (is_list) resolved = true;
+            if (walking) {
+                in_walk = accel_walk_decide<F>(best, t_last, slack_t, ended) == kWalkGoesOn;
+                resolved = !in_walk;
+            }
+            if (VERIFY && resolved) { // test build of the kernel: lists and walks must reproduce the full sequential scan
+                const HitInfo<F> full = sequential_closest_hit<F>(P, path, a, t_min);
+                if (full.idx != best.idx || !(full.t == best.t)) atomicAdd(&P.counters[2], 1ull);
+            }
+            if (__builtin_expect(need_scan, 0)) { // a ray the unordered rule is not proven for: the reference's scan, in its order
+                best = sequential_closest_hit<F>(P, path, a, t_min);
+                n_scanned += 1;
+                resolved = true;
+            }
+            // ---------------- shade: rrt.cu:49-76 -------------------------------------------------
+            RRTX_SEC(5);
+            if (resolved) done = shade<F, SO>(P, best, path, rng, radiance);
+            RRTX_SEC(6); // sample / task bookkeeping, stores
+            if (done) {
+                acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
+                s_cur += 1;
+                if (s_cur == s_end) {
+                    F *o = RESUME ? P.tail_rad + (size_t)out_index * 3 : task_slot<F>(*cold_params<F>(), task);
+                    o[0] = acc.x;
+                    o[1] = acc.y;
+                    o[2] = acc.z;
+                    need_task = true;
+                }
+                else
+                    need_ray = true;
+            }
+        }
     }
 
     if (P.collect_stats) {
@@ -793,7 +1054,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
 #else
     if (lane == 0 && !RESUME)
 #endif
-        for (int k = 0; k < 8; ++k) atomicAdd(&P.counters[16 + k], sec_cycles[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&P.counters[16 + k], sec_cycles[k]), atomicAdd(&P.counters[8 + k], dense_dbg[k]);
 #endif
 #undef RRTX_SEC
 #ifdef RRTX_DIAG

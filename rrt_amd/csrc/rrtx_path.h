@@ -576,6 +576,154 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
     return kWalkGoesOn;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same walk, cut differently: accel_walk_prepare() runs everything of a slice that does NOT depend on the
+// slice's own tests - the always-list and the box clip of a new segment, then the DDA through up to `max_cells`
+// cells - and returns the cells' entry lists as up to four (first, count) ranges of cell_prims instead of testing
+// them; the caller tests those entries in ANY order with test_primitive() / consider() (the render kernel: all 64
+// lanes of the wave share out the (ray, entry) pairs of all its lanes, see dense_candidates there) and then asks
+// accel_walk_decide() whether the walk goes on.  Against accel_closest_hit() a lane may so test cells that lie
+// beyond a hit found earlier in the same slice - a superset of its tests, hence, by the order-independence above,
+// the same answer; where a slice ends the two make the same decision with the same `best`.
+// A cell of more than kDenseCellMax entries is tested here, by its lane alone (counts are packed in 8 bits).
+// ---------------------------------------------------------------------------------------------
+struct WalkRanges {
+    uint32_t beg0, beg1, beg2, beg3; // first entry of each range (an index into cell_prims)
+    uint32_t cnt;                    // entries per range, 8 bits each; ranges are filled from 0 up
+};
+constexpr uint32_t kDenseCellMax = 60;
+constexpr int kDenseRanges = 4;
+template <typename F, bool SO = false, typename PP, typename HotTab, typename CellTab, typename PrimTab>
+RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
+                                uint32_t &walk_cell, F &walk_t_out, int max_cells, WalkRanges &R, F &t_last, F &slack_out, bool &ended)
+{
+    R.beg0 = R.beg1 = R.beg2 = R.beg3 = 0u, R.cnt = 0u;
+    t_last = 0, slack_out = 0, ended = true;
+    const F ox = path.o.x, oy = path.o.y, oz = path.o.z, dx = path.d.x, dy = path.d.y, dz = path.d.z;
+    const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
+    const F dist2 = rx * rx + ry * ry + rz * rz;
+    const F reach = P.grid.slack1 * (approx_sqrt(dist2) + P.grid.half_diag);
+    const int tri_base_ = SO ? kNoTriangles : P.n_sph_padded + P.n_msph;
+    PendingRoot<F> pend = {-1, 0, 0};
+    const F o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    F inv[3], tmax[3];
+    int ci[3];
+    F t_out = walk_t_out;
+    bool par[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) par[k] = !(ffabs(d[k]) >= Limits<F>::coop_tiny()), inv[k] = par[k] ? Limits<F>::inf() : approx_rcp(d[k]);
+    if (!resume) {
+        {
+            const F o2 = ox * ox + oy * oy + oz * oz;
+            const bool ok = a >= Limits<F>::coop_tiny() && a <= P.grid.dir2_max && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big() && dist2 <= Limits<F>::coop_big();
+            if (!ok) return kWalkNeedsScan;
+        }
+#ifdef RRTX_CONST_AS
+        const RRTX_CONST_AS uint32_t *always = (const RRTX_CONST_AS uint32_t *)P.grid_always;
+#else
+        const uint32_t *always = P.grid_always;
+#endif
+        for (int i = 0; i < P.n_always; ++i) test_primitive<F, SO>(P, hot, (int)always[i], path, a, t_min, best, pend);
+        resolve_pending<F>(pend, a, t_min, tri_base_, best);
+        const bool is_far = dist2 > P.grid.far2;
+        const F fat = is_far ? reach + reach : (F)0;
+        F t_in = 0;
+        t_out = Limits<F>::inf();
+        bool miss = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const F glo = P.grid.gmin[k] - fat, ghi = P.grid.gmax[k] + fat;
+            if (!par[k]) {
+                const F t1 = (glo - o[k]) * inv[k], t2 = (ghi - o[k]) * inv[k];
+                const F lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+                t_in = lo > t_in ? lo : t_in;
+                t_out = hi < t_out ? hi : t_out;
+            }
+            else if (o[k] < glo || o[k] > ghi)
+                miss = true;
+        }
+        if (miss || !(t_in <= t_out * ((F)1 + (F)1e-3))) return kWalkDone;
+        if (is_far) return kWalkFarScan;
+        if (t_in > best.t + (P.grid.slack + reach) * approx_rsqrt(a)) return kWalkDone;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const F pk = o[k] + d[k] * t_in;
+            int c = (int)((pk - P.grid.gmin[k]) * P.grid.inv_cell[k]);
+            ci[k] = c < 0 ? 0 : (c > P.grid.dims[k] - 1 ? P.grid.dims[k] - 1 : c);
+        }
+    }
+    else
+        ci[0] = (int)(walk_cell & 1023u), ci[1] = (int)((walk_cell >> 10) & 1023u), ci[2] = (int)(walk_cell >> 20);
+    const F slack_t = (P.grid.slack + reach) * approx_rsqrt(a);
+    slack_out = slack_t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tmax[k] = par[k] ? Limits<F>::inf() : (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k];
+    const F dtx = P.grid.cell[0] * ffabs(inv[0]), dty = P.grid.cell[1] * ffabs(inv[1]), dtz = P.grid.cell[2] * ffabs(inv[2]);
+    const int sx = dx > 0 ? 1 : -1, sy = dy > 0 ? 1 : -1, sz = dz > 0 ? 1 : -1;
+    int nr = 0;
+    ended = false;
+    for (int step = 0; step < max_cells && nr < kDenseRanges; ++step) {
+        const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
+        const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
+        const uint32_t n = end - beg;
+        if (n > kDenseCellMax) { // a crowded cell: its lane tests it alone, here and now
+            for (uint32_t k = beg; k < end; ++k) test_primitive<F, SO>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
+            resolve_pending<F>(pend, a, t_min, tri_base_, best);
+        }
+        else if (n != 0u) {
+            R.beg0 = nr == 0 ? beg : R.beg0, R.beg1 = nr == 1 ? beg : R.beg1, R.beg2 = nr == 2 ? beg : R.beg2, R.beg3 = nr == 3 ? beg : R.beg3;
+            R.cnt |= n << (8 * nr);
+            nr += 1;
+        }
+        const bool ax = tmax[0] <= tmax[1] && tmax[0] <= tmax[2];
+        const bool ay = !ax && tmax[1] <= tmax[2];
+        const bool az = !ax && !ay;
+        const F t_next = ax ? tmax[0] : (ay ? tmax[1] : tmax[2]);
+        t_last = t_next;
+        if (t_next > t_out || t_next > best.t + slack_t) {
+            ended = true;
+            break;
+        }
+        ci[0] += ax ? sx : 0, ci[1] += ay ? sy : 0, ci[2] += az ? sz : 0;
+        tmax[0] += ax ? dtx : (F)0, tmax[1] += ay ? dty : (F)0, tmax[2] += az ? dtz : (F)0;
+        if ((uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2]) {
+            ended = true;
+            break;
+        }
+    }
+    walk_cell = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
+    walk_t_out = t_out;
+    return kWalkGoesOn; // ranges are out (possibly none): test them, then accel_walk_decide()
+}
+// After the entries of accel_walk_prepare()'s ranges went through test_primitive() / resolve_pending(): is `best` final?
+template <typename F> RRTX_DEV int accel_walk_decide(const HitInfo<F> &best, F t_last, F slack_t, bool ended) { return (ended || t_last > best.t + slack_t) ? kWalkDone : kWalkGoesOn; }
+// entry j of a lane's ranges -> index into cell_prims (j < the sum of the counts)
+RRTX_DEV uint32_t walk_range_entry(uint32_t beg0, uint32_t beg1, uint32_t beg2, uint32_t beg3, uint32_t cnt, uint32_t j)
+{
+    const uint32_t c0 = cnt & 255u, c1 = (cnt >> 8) & 255u, c2 = (cnt >> 16) & 255u;
+    const uint32_t e1 = c0 + c1, e2 = e1 + c2;
+    return j < c0 ? beg0 + j : (j < e1 ? beg1 + (j - c0) : (j < e2 ? beg2 + (j - e1) : beg3 + (j - e2)));
+}
+RRTX_DEV uint32_t walk_range_total(uint32_t cnt) { return (cnt & 255u) + ((cnt >> 8) & 255u) + ((cnt >> 16) & 255u) + (cnt >> 24); }
+// The batched walk as ONE lane runs it (the statement tests/path_host_check.cpp holds against the sequential scan):
+// prepare a slice, test its entries, decide.
+template <typename F, bool SO = false, typename PP, typename HotTab, typename CellTab, typename PrimTab>
+RRTX_DEV int accel_closest_hit_batched(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
+                                       uint32_t &walk_cell, F &walk_t_out, int max_cells)
+{
+    WalkRanges R;
+    F t_last, slack_t;
+    bool ended;
+    const int r = accel_walk_prepare<F, SO>(P, hot, cell_start, cell_prims, path, a, t_min, best, resume, walk_cell, walk_t_out, max_cells, R, t_last, slack_t, ended);
+    if (r != kWalkGoesOn) return r;
+    PendingRoot<F> pend = {-1, 0, 0};
+    const uint32_t n = walk_range_total(R.cnt);
+    for (uint32_t j = n; j-- > 0u;) // (backwards: any order must do)
+        test_primitive<F, SO>(P, hot, (int)cell_prims[walk_range_entry(R.beg0, R.beg1, R.beg2, R.beg3, R.cnt, j)], path, a, t_min, best, pend);
+    resolve_pending<F>(pend, a, t_min, SO ? kNoTriangles : P.n_sph_padded + P.n_msph, best);
+    return accel_walk_decide<F>(best, t_last, slack_t, ended);
+}
+
 // Per-segment half of the conservative scan filter (see the render kernel's phase 1 and DESIGN.md
 // "Conservative scan filter"): with n = d/|d|, u = c.n, s = o.n,
 //   disc/|d|^2 = u^2 + 2(o - s n).c + (s^2 - |o|^2) + (r^2 - |c|^2);

@@ -155,7 +155,7 @@ template <typename F> static int run(const char *name, int variant, long n_rays,
     }
     std::uniform_real_distribution<double> U(0.0, 1.0);
     std::normal_distribution<double> N(0.0, 1.0);
-    long mismatches = 0, walked = 0, scanned = 0, sliced_diff = 0;
+    long mismatches = 0, walked = 0, scanned = 0, sliced_diff = 0, batched_diff = 0;
     const F t_min = (F)0.001;
     for (long i = 0; i < n_rays; ++i) {
         Path<F> path = {};
@@ -233,10 +233,20 @@ template <typename F> static int run(const char *name, int variant, long n_rays,
             resume = true;
         }
         if (r != kWalkDone || b2.idx != want.idx || !(b2.t == want.t)) sliced_diff += 1;
+        // ... and the batched walk (the render kernel's: a slice's cells are listed first, their entries tested afterwards in any
+        // order - here backwards -, then the decision): same answer, same slice boundaries
+        HitInfo<F> b3 = {std::numeric_limits<F>::infinity(), -1};
+        resume = false;
+        for (int guard = 0; guard < 100000; ++guard) {
+            r = accel_closest_hit_batched<F>(s.P, s.hot.data(), s.cell_start.data(), s.cell_prims.data(), path, a, t_min, b3, resume, cell, t_out, slice);
+            if (r != kWalkGoesOn) break;
+            resume = true;
+        }
+        if (r != kWalkDone || b3.idx != want.idx || !(b3.t == want.t)) batched_diff += 1;
     }
-    std::printf("%s variant %d: grid %d x %d x %d, %d entries, %d always, far %.4g | %ld rays walked, %ld left to the scan, %ld mismatches, %ld sliced-walk mismatches\n", name, variant,
-                s.P.grid.dims[0], s.P.grid.dims[1], s.P.grid.dims[2], s.P.n_grid_prims, s.P.n_always, std::sqrt((double)s.P.grid.far2), walked, scanned, mismatches, sliced_diff);
-    return mismatches != 0 || sliced_diff != 0 || walked == 0;
+    std::printf("%s variant %d: grid %d x %d x %d, %d entries, %d always, far %.4g | %ld rays walked, %ld left to the scan, %ld mismatches, %ld sliced-walk mismatches, %ld batched-walk mismatches\n", name, variant,
+                s.P.grid.dims[0], s.P.grid.dims[1], s.P.grid.dims[2], s.P.n_grid_prims, s.P.n_always, std::sqrt((double)s.P.grid.far2), walked, scanned, mismatches, sliced_diff, batched_diff);
+    return mismatches != 0 || sliced_diff != 0 || batched_diff != 0 || walked == 0;
 }
 
 int main(int argc, char **argv)
