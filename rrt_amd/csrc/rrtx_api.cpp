@@ -207,8 +207,8 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
             if ((rc = up((void **)&c->d_grid_cell_start, cell_start.data(), cell_start.size() * 4))) return rc;
             if ((rc = up((void **)&c->d_grid_cell_prims, cell_prims.data(), cell_prims.size() * sizeof(GridPrim)))) return rc;
             if ((rc = up((void **)&c->d_grid_always, always.data(), always.size() * 4))) return rc;
-            c->n_grid_cells = (int)cell_start.size() - 1;
-            c->n_grid_prims = (int)cell_start.back();
+            c->n_grid_cells = (int)G.dims[0] * (int)G.dims[1] * (int)G.dims[2]; // (cell_start may carry the coarse occupancy bytes behind its cells + 1 words)
+            c->n_grid_prims = (int)cell_start[(size_t)c->n_grid_cells];
             memcpy(c->grid_bytes, &G, sizeof G);
             c->accel = c->p.use_bvh != 0 && !degenerate;
             c->tail_grid = !c->accel;

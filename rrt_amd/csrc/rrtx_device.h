@@ -116,6 +116,11 @@ template <typename F> struct GridRec {
     int32_t max_steps;   // bound on the trips of the walk (cells stepped through + primitives tested)
     F dir2_max;          // rays with |d|^2 above this take the list scan: the inflation of gridded triangles is proven up to it
     int32_t walk_slice;  // cells a lane walks per iteration of the render loop before the others get their turn (4 .. 16)
+    // Empty-space skipping (large, mostly empty grids: meshes): one byte per block of 4 x 4 x 4 cells - does any of them hold an entry? -
+    // stored behind cell_start's cells + 1 words, from word coarse_off on (0: none).  The batched walk (accel_walk_prepare) crosses an empty
+    // block in ONE step.
+    int32_t coarse_dims[3];
+    int32_t coarse_off;
 };
 
 // Division by a launch constant: n / d == umulhi(n, m) >> shift for every n < 2^31 (m = floor(2^(31 + L) / d) + 1,

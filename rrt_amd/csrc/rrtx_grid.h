@@ -9,10 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <cstring>
 #include <vector>
 
 #include "rrtx_device.h"
 
+#ifndef RRTX_GRID_COARSE_ALWAYS // 1: every grid gets the coarse occupancy bytes (tests/path_host_check.cpp: the skipping on small grids too)
+#define RRTX_GRID_COARSE_ALWAYS 0
+#endif
 #ifndef RRTX_GRID_SLICE_OVERRIDE
 #define RRTX_GRID_SLICE_OVERRIDE 0
 #endif
@@ -348,6 +352,24 @@ inline bool build_grid(const std::vector<SphereHot<F>> &hot, const std::vector<S
             size_t empty = 0;
             for (int q = 0; q < ncell; ++q) empty += cell_start[q + 1] == cell_start[q];
             G.walk_slice = RRTX_GRID_SLICE_OVERRIDE > 0 ? RRTX_GRID_SLICE_OVERRIDE : (2 * empty > (size_t)ncell && dims[0] + dims[1] + dims[2] >= 128 ? 16 : 4);
+        }
+        // empty-space skipping for the grids that got long slices (see rrtx_device.h, GridRec::coarse_off)
+        G.coarse_off = 0, G.coarse_dims[0] = G.coarse_dims[1] = G.coarse_dims[2] = 0;
+        if (RRTX_GRID_COARSE_ALWAYS || (G.walk_slice > 4 && grid_knob("RRTX_GRID_COARSE", 0.0) != 0.0)) { // (off in the product: measured slower, rrtx_kernels.hip)
+            const int cd[3] = {(dims[0] + 3) / 4, (dims[1] + 3) / 4, (dims[2] + 3) / 4};
+            std::vector<uint8_t> occ((size_t)cd[0] * cd[1] * cd[2], 0);
+            for (int iz = 0; iz < dims[2]; ++iz)
+                for (int iy = 0; iy < dims[1]; ++iy)
+                    for (int ix = 0; ix < dims[0]; ++ix) {
+                        const int q = (iz * dims[1] + iy) * dims[0] + ix;
+                        if (cell_start[q + 1] != cell_start[q]) occ[((size_t)(iz / 4) * cd[1] + iy / 4) * cd[0] + ix / 4] = 1;
+                    }
+            G.coarse_off = ncell + 1;
+            for (int k = 0; k < 3; ++k) G.coarse_dims[k] = cd[k];
+            const size_t words = (occ.size() + 3) / 4;
+            const size_t at = cell_start.size();
+            cell_start.resize(at + words, 0u);
+            memcpy(&cell_start[at], occ.data(), occ.size());
         }
         if (grid_knob("RRTX_DEBUG_GRID", 0.0) != 0.0)
             fprintf(stderr, "rrtx grid: cell %g dims %d x %d x %d, %zu entries, %zu always, largest inflation %g, half diagonal %g, far %g, centre %g %g %g\n", cell, dims[0], dims[1], dims[2],

@@ -169,6 +169,12 @@ template <typename F> struct ScanType<F, true> {
 #ifndef RRTX_WALK_SLICE
 #define RRTX_WALK_SLICE 0 // > 0 overrides GridRec::walk_slice, the cells a lane walks per iteration of the render loop (final.txt: 2 / 3 / 4 / 6 / all: 49.4 / 45.5 / 45.1 / 46.2 / 50.0 ms)
 #endif
+#ifndef RRTX_DENSE_WAVES
+#define RRTX_DENSE_WAVES 4 // ... the variants that pair (ray, entry) densely (scenes with triangles / moving spheres): their launches are bound by the latency of dependent loads, not by occupancy, and at 80 registers they spilled 60
+#endif
+#ifndef RRTX_DENSE_WAVES_F64
+#define RRTX_DENSE_WAVES_F64 2 // (fp64 mesh 600x400 spp 16: 2 / 3 / 4 waves per SIMD 19.9 / 21.9 - 23.7 / 22.7 ms; fp32: 3 / 4 / 5 / 6 -> 16.4 / 16.0 / 17.3 / 27.5)
+#endif
 #ifndef RRTX_ACCEL_WAVES
 #define RRTX_ACCEL_WAVES 6 // waves per SIMD the accelerated fp32 variants are compiled for (80 VGPRs: 43.6 vs 45.5 ms without the limit)
 #endif
@@ -241,21 +247,24 @@ template <typename F> __device__ __forceinline__ HitInfo<F> sequential_closest_h
 // (+ every moving sphere and triangle, as the LIST passes of the list-scan kernel test them) - and the wave then shares all
 // those (ray, entry) pairs out evenly: pair p = base + lane of a trip belongs to the lane whose range [off, off + n) of the
 // prefix sum holds p (found with one mark per owner in LDS and a prefix maximum), its ray comes across with ds_bpermute, and
-// the lane evaluates the exact test's REJECTION part for it - the discriminant of sphere.h:35-41, the a / u / v cuts of
-// triangle.h:38-56 - with the owner's operands in the owner's arithmetic.  Pairs that are not rejected are pushed onto the
-// owner's candidate list in LDS (an atomic slot counter per owner), and each owner afterwards runs the full exact test on its
-// few candidates with consider()'s order-independent rule - the answer of the sequential scan (rrtx_path.h).  More than CAP
-// candidates for one owner: that lane tests its own entries itself.
-// All 64 lanes call this, converged.  marks / cnts: 64 dwords of LDS each, this wave's; cand: CAP x 64 dwords, slot s of lane
-// l at cand[s * 64 + l].
+// the lane evaluates the reference's exact test for it (sphere.h:33-49, moving_sphere.h:27-49, triangle.h:35-71) with the owner's
+// operands in the owner's arithmetic - the same operations in the same order as test_primitive(), so the same bits.  A pair that
+// yields a hit (t >= t_min; the window's far end is the owner's business) is folded into the owner's slot in LDS with an atomic
+// minimum under consider()'s order - the smallest t; at equal t the sphere-like primitive of the highest index, a triangle only
+// if no sphere has that t, and then the one of the lowest index (rrtx_path.h) - which is the answer of the sequential scan whatever
+// order the hits arrive in.  fp32: ONE ds_min_u64 on (bits of t << 32 | ~rank) - t is positive, so its bits order like its value.
+// fp64: a ds_min_u64 on the bits of t, then the lanes whose t IS the owner's minimum raise the owner's rank with a ds_max_u32
+// (the rank slot cleared first by whoever lowered the minimum in this trip).  The owner reads its slot when the trips are over.
+// All 64 lanes call this, converged.  marks, ranks: 64 dwords of LDS each, keys: 64 qwords, this wave's.
 // ---------------------------------------------------------------------------------------------
 template <typename F, bool SO, int CAP, typename HotTab, typename PrimTab>
 __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const HotTab &hot, const PrimTab &cell_prims, const uint16_t *plist, const Path<F> &path, F a, const WalkRanges &R,
-                                                  bool is_list, uint32_t n_own, int lane, uint32_t *marks, uint32_t *cnts, uint32_t *cand)
+                                                  F t_min, bool is_list, uint32_t n_own, int lane, uint32_t *marks, uint32_t *ranks, unsigned long long *keys)
 {
     const uint32_t incl = wave_scan_add(n_own), off = incl - n_own;
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    cnts[lane] = 0u;
+    keys[lane] = ~0ull;
+    if (sizeof(F) == 8) ranks[lane] = 0u;
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
     const uint32_t off_and_kind = off | (is_list ? 0x80000000u : 0u);
     for (uint32_t base = 0; base < total; base += 64u) {
@@ -276,6 +285,9 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
         rp.tm = SO ? (F)0 : __shfl(path.tm, owner);
         rp.atten = mk<F>(0, 0, 0), rp.depth = 0;
         const F ra = __shfl(a, owner);
+        bool keep = false;
+        F t_hit = 0;
+        uint32_t rank_u = 0; // consider()'s rank, biased to unsigned: spheres by index, triangles below all spheres and by descending index
         if (live) {
             const uint32_t j = p - (o_ok & 0x7FFFFFFFu);
             const uint32_t e = walk_range_entry(o_b0, o_b1, o_b2, o_b3, o_cnt, j);
@@ -286,36 +298,54 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
                 idx = (int)plist[(size_t)o_b0 * kPlistStride + 1u + j]; // range 0 of a camera ray: its pixel's list (beg0 = the pixel)
             else
                 idx = (int)e; // ranges 1, 2 of a camera ray: every moving sphere, every triangle
-            bool keep;
-            if (SO || idx < msph_base) {
-                const SphereHot<F> g = hot[idx];
-                const F ocx = rp.o.x - g.cx, ocy = rp.o.y - g.cy, ocz = rp.o.z - g.cz; // sphere.h:35-40
+            rank_u = (uint32_t)((SO || idx < tri_base) ? idx : -idx - 1) ^ 0x80000000u;
+            if (SO || idx < tri_base) {
+                F cx, cy, cz, r2;
+                if (SO || idx < msph_base) {
+                    const SphereHot<F> g = hot[idx];
+                    cx = g.cx, cy = g.cy, cz = g.cz, r2 = g.r2;
+                }
+                else {
+                    const MovingSphereRec<F> ms = P.msph[idx - msph_base];
+                    const V3<F> cen = msphere_center<F>(ms, rp.tm);
+                    cx = cen.x, cy = cen.y, cz = cen.z, r2 = ms.r2;
+                }
+                const F ocx = rp.o.x - cx, ocy = rp.o.y - cy, ocz = rp.o.z - cz; // sphere.h:35-40
                 const F half_b = ocx * rp.d.x + ocy * rp.d.y + ocz * rp.d.z;
-                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.r2;
-                keep = !(half_b * half_b - ra * c < 0);
+                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
+                const F disc = half_b * half_b - ra * c;
+                keep = !(disc < 0);
+                if (keep) { // sphere.h:41-49 without the dependence on the scan order (resolve_pending)
+                    const F sq = fsqrt(disc);
+                    t_hit = (-half_b - sq) / ra;
+                    if (t_hit < t_min) {
+                        t_hit = (-half_b + sq) / ra;
+                        keep = !(t_hit < t_min);
+                    }
+                }
             }
-            else if (idx < tri_base) {
-                const MovingSphereRec<F> ms = P.msph[idx - msph_base];
-                const V3<F> cen = msphere_center<F>(ms, rp.tm);
-                const F ocx = rp.o.x - cen.x, ocy = rp.o.y - cen.y, ocz = rp.o.z - cen.z;
-                const F half_b = ocx * rp.d.x + ocy * rp.d.y + ocz * rp.d.z;
-                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - ms.r2;
-                keep = !(half_b * half_b - ra * c < 0);
-            }
-            else {
-                F dummy;
-                keep = triangle_test<F, false>(P.tri[idx - tri_base], rp, (F)0, (F)0, dummy);
-            }
-            if (keep) {
-                const uint32_t slot = atomicAdd(&cnts[owner], 1u); // ds_add_rtn_u32
-                if (slot < (uint32_t)CAP) cand[slot * 64u + (uint32_t)owner] = (uint32_t)idx;
-            }
+            else
+                keep = triangle_test<F, true>(P.tri[idx - tri_base], rp, t_min, Limits<F>::inf(), t_hit);
+        }
+        if (sizeof(F) == 4) {
+            if (keep) atomicMin(&keys[owner], ((unsigned long long)__float_as_uint((float)t_hit) << 32) | (unsigned long long)(~rank_u)); // ds_min_u64
+        }
+        else {
+            const unsigned long long tb = (unsigned long long)__double_as_longlong((double)t_hit);
+            const unsigned long long before = keys[owner];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (keep) atomicMin(&keys[owner], tb);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool wins = keep && keys[owner] == tb; // this pair's t is the owner's minimum so far
+            if (wins && tb < before) ranks[owner] = 0u;  // ... a new one: what the slot says belongs to a larger t
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (wins) atomicMax(&ranks[owner], rank_u + 1u);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? RRTX_ACCEL_WAVES : RRTX_ACCEL_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -329,7 +359,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     // the per-lane walk, everything else is paired densely.
     constexpr bool kDensePairs = ACCEL != 0 && !SO;
     constexpr int kDenseLds = kDensePairs ? 64 : 1;
-    __shared__ uint32_t dense_marks[kWavesPerBlock][kDenseLds], dense_cnts[kWavesPerBlock][kDenseLds];
+    __shared__ uint32_t dense_marks[kWavesPerBlock][kDenseLds], dense_ranks[kWavesPerBlock][kDenseLds];
+    __shared__ unsigned long long dense_keys[kWavesPerBlock][kDenseLds];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     typedef typename ScanType<F, FILTER>::type ST; // precision of the scan's records: the filter is fp32 for every F
     SphereHot<ST> *const sph_lds = (SphereHot<ST> *)dyn_lds;
@@ -932,10 +963,14 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 }
                 else {
                     int r;
+                    // (empty-space skipping - an occupancy byte per block of 4 x 4 x 4 cells, empty blocks crossed in one step: accel_walk_prepare, checked
+                    // on the host - measured on the 27 072-triangle mesh with the bytes read from HBM: 16.0 -> 20.1 ms, fp64 21.9 -> 23.9; the look-up is one
+                    // more dependent load per step and the jump costs more instructions than the 2 - 3 empty cells it saves.  Not used: EXPERIMENTS.md)
+                    const uint8_t *coarse = nullptr;
                     if (ACCEL == 2)
-                        r = accel_walk_prepare<F, SO>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended);
+                        r = accel_walk_prepare<F, SO>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended, coarse);
                     else
-                        r = accel_walk_prepare<F, SO>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended);
+                        r = accel_walk_prepare<F, SO>(C, P.sph_hot, P.grid_cell_start, P.grid_cell_prims, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended, coarse);
                     if (r == kWalkDone)
                         resolved = true, in_walk = false;
                     else if (r == kWalkNeedsScan)
@@ -950,52 +985,33 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             RRTX_SEC(7);
             const uint32_t n_own = walk_range_total(R.cnt);
             if (ACCEL == 2)
-                dense_candidates<F, SO, kCap>(P, hot_lds, cell_prims_lds, C.plist, path, a, R, is_list, n_own, lane, &dense_marks[wave][0], &dense_cnts[wave][0], &cand_lds[wave][0][0]);
+                dense_candidates<F, SO, kCap>(P, hot_lds, cell_prims_lds, C.plist, path, a, R, t_min, is_list, n_own, lane, &dense_marks[wave][0], &dense_ranks[wave][0], &dense_keys[wave][0]);
             else
-                dense_candidates<F, SO, kCap>(P, P.sph_hot, P.grid_cell_prims, C.plist, path, a, R, is_list, n_own, lane, &dense_marks[wave][0], &dense_cnts[wave][0], &cand_lds[wave][0][0]);
-            // ---- every owner: the exact test of its candidates, in any order
+                dense_candidates<F, SO, kCap>(P, P.sph_hot, P.grid_cell_prims, C.plist, path, a, R, t_min, is_list, n_own, lane, &dense_marks[wave][0], &dense_ranks[wave][0], &dense_keys[wave][0]);
+            // ---- every owner: its hits, in any order
             RRTX_SEC(3);
+            if (n_own != 0u) {
+                const unsigned long long k = dense_keys[wave][lane];
+                if (k != ~0ull) {
+                    F t_hit;
+                    uint32_t rank_u;
+                    if (sizeof(F) == 4)
+                        t_hit = (F)__uint_as_float((uint32_t)(k >> 32)), rank_u = ~(uint32_t)k;
+                    else
+                        t_hit = (F)__longlong_as_double((long long)k), rank_u = dense_ranks[wave][lane] - 1u;
+                    const int r = (int)(rank_u ^ 0x80000000u);
+                    consider<F>(t_hit, r >= 0 ? r : -r - 1, SO ? kNoTriangles : tri_base, best);
+                    n_candidates += 1;
+                }
+            }
 #ifdef RRTX_SECTION_DIAG // developer builds: what the dense pairing is fed, per wave and iteration -> counters[8 + k]
             {
-                const uint32_t c_dbg = n_own != 0u ? dense_cnts[wave][lane] : 0u;
-                uint32_t pairs_dbg = n_own, cmax_dbg = c_dbg, csum_dbg = c_dbg;
-                for (int off_dbg = 32; off_dbg >= 1; off_dbg >>= 1) {
-                    pairs_dbg += __shfl_xor(pairs_dbg, off_dbg), csum_dbg += __shfl_xor(csum_dbg, off_dbg);
-                    const uint32_t o_dbg = __shfl_xor(cmax_dbg, off_dbg);
-                    cmax_dbg = o_dbg > cmax_dbg ? o_dbg : cmax_dbg;
-                }
-                dense_dbg[0] += 1, dense_dbg[1] += (pairs_dbg + 63u) / 64u, dense_dbg[2] += pairs_dbg, dense_dbg[3] += csum_dbg, dense_dbg[4] += cmax_dbg;
-                dense_dbg[5] += (unsigned long long)__popcll(__ballot(c_dbg > (uint32_t)kCap)), dense_dbg[6] += (unsigned long long)__popcll(__ballot(walking)), dense_dbg[7] += (unsigned long long)__popcll(__ballot(is_list));
+                uint32_t pairs_dbg = n_own;
+                for (int off_dbg = 32; off_dbg >= 1; off_dbg >>= 1) pairs_dbg += __shfl_xor(pairs_dbg, off_dbg);
+                dense_dbg[0] += 1, dense_dbg[1] += (pairs_dbg + 63u) / 64u, dense_dbg[2] += pairs_dbg;
+                dense_dbg[6] += (unsigned long long)__popcll(__ballot(walking)), dense_dbg[7] += (unsigned long long)__popcll(__ballot(is_list));
             }
 #endif
-            if (n_own != 0u) {
-                PendingRoot<F> pend = {-1, 0, 0};
-                const uint32_t c = dense_cnts[wave][lane];
-                n_candidates += c;
-                auto exact = [&](int idx) {
-                    if (ACCEL == 2)
-                        test_primitive<F, SO>(P, hot_lds, idx, path, a, t_min, best, pend);
-                    else
-                        test_primitive<F, SO>(P, P.sph_hot, idx, path, a, t_min, best, pend);
-                };
-                if (c <= (uint32_t)kCap) {
-                    for (uint32_t k = 0; k < c; ++k) exact((int)my_cand[k * 64]);
-                }
-                else { // more candidates than slots (a ray through a pile of primitives): this lane goes through its own entries
-                    for (uint32_t j = 0; j < n_own; ++j) {
-                        const uint32_t e = walk_range_entry(R.beg0, R.beg1, R.beg2, R.beg3, R.cnt, j);
-                        int idx;
-                        if (!is_list)
-                            idx = ACCEL == 2 ? (int)cell_prims_lds[e] : (int)P.grid_cell_prims[e];
-                        else if (j < (R.cnt & 255u))
-                            idx = (int)C.plist[(size_t)R.beg0 * kPlistStride + 1u + j];
-                        else
-                            idx = (int)e;
-                        exact(idx);
-                    }
-                }
-                resolve_pending<F>(pend, a, t_min, SO ? kNoTriangles : tri_base, best);
-            }
             RRTX_SEC(4);
             if (is_list) resolved = true;
             if (walking) {
@@ -1626,12 +1642,15 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
     if (P.grid_cell_start) {
         const size_t alds = accel_lds_bytes<F>(P);
-        // (the variants for scenes of spheres alone are compiled under the same launch bounds: the same occupancy)
-        if (!filter)
-            return alds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 2>, kBlockThreads, alds)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 1>, kBlockThreads, 0);
-        return alds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 2>, kBlockThreads, alds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 1>, kBlockThreads, 0);
+        // (the variants for scenes of spheres alone and the densely pairing ones are compiled under different launch bounds)
+        const bool so = P.n_msph == 0 && P.n_tri == 0;
+        auto occ = [&](auto kernel, size_t lds) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, kBlockThreads, lds); };
+        if (!filter) {
+            if (so) return alds ? occ(render_kernel<F, false, 0, false, 2, false, true>, alds) : occ(render_kernel<F, false, 0, false, 1, false, true>, 0);
+            return alds ? occ(render_kernel<F, false, 0, false, 2, false, false>, alds) : occ(render_kernel<F, false, 0, false, 1, false, false>, 0);
+        }
+        if (so) return alds ? occ(render_kernel<F, true, 0, false, 2, false, true>, alds) : occ(render_kernel<F, true, 0, false, 1, false, true>, 0);
+        return alds ? occ(render_kernel<F, true, 0, false, 2, false, false>, alds) : occ(render_kernel<F, true, 0, false, 1, false, false>, 0);
     }
     if (!filter) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, false, 0, false, 0>, kBlockThreads, 0);
     switch (lds_mode) {

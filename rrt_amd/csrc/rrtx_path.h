@@ -595,7 +595,7 @@ constexpr uint32_t kDenseCellMax = 60;
 constexpr int kDenseRanges = 4;
 template <typename F, bool SO = false, typename PP, typename HotTab, typename CellTab, typename PrimTab>
 RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
-                                uint32_t &walk_cell, F &walk_t_out, int max_cells, WalkRanges &R, F &t_last, F &slack_out, bool &ended)
+                                uint32_t &walk_cell, F &walk_t_out, int max_cells, WalkRanges &R, F &t_last, F &slack_out, bool &ended, const uint8_t *coarse = nullptr)
 {
     R.beg0 = R.beg1 = R.beg2 = R.beg3 = 0u, R.cnt = 0u;
     t_last = 0, slack_out = 0, ended = true;
@@ -660,37 +660,101 @@ RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &c
     for (int k = 0; k < 3; ++k) tmax[k] = par[k] ? Limits<F>::inf() : (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k];
     const F dtx = P.grid.cell[0] * ffabs(inv[0]), dty = P.grid.cell[1] * ffabs(inv[1]), dtz = P.grid.cell[2] * ffabs(inv[2]);
     const int sx = dx > 0 ? 1 : -1, sy = dy > 0 ? 1 : -1, sz = dz > 0 ? 1 : -1;
-    int nr = 0;
+    // The cells come in batches of kWalkBatch: first the DDA alone runs through the batch (which cells, where each ends, whether the
+    // walk ends there - nothing of that depends on what the cells hold), then the batch's list headers are fetched TOGETHER, then they
+    // are taken up in order.  With the grid in HBM a header is a dependent load of several hundred clocks, and a walk through a large,
+    // mostly empty grid (a mesh: slices of 16 cells) used to pay them one after the other.
+    constexpr int kWalkBatch = 4;
+    int nr = 0, steps_left = max_cells;
+    uint32_t pos = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
     ended = false;
-    for (int step = 0; step < max_cells && nr < kDenseRanges; ++step) {
-        const uint32_t cell = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
-        const uint32_t beg = cell_start[cell], end = cell_start[cell + 1];
-        const uint32_t n = end - beg;
-        if (n > kDenseCellMax) { // a crowded cell: its lane tests it alone, here and now
-            for (uint32_t k = beg; k < end; ++k) test_primitive<F, SO>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
-            resolve_pending<F>(pend, a, t_min, tri_base_, best);
+    while (steps_left > 0 && nr < kDenseRanges && !ended) {
+        uint32_t cellv[kWalkBatch], nextv[kWalkBatch];
+        F tnv[kWalkBatch];
+        bool endv[kWalkBatch];
+        int m = 0;
+        bool stop = false;
+#pragma unroll
+        for (int q = 0; q < kWalkBatch; ++q) {
+            cellv[q] = 0u, nextv[q] = 0u, tnv[q] = 0, endv[q] = false;
+            if (q < steps_left && !stop) {
+                // (an empty block of 4 x 4 x 4 cells is crossed in one step: GridRec::coarse_off)
+                bool jump = false;
+                int cc[3] = {0, 0, 0};
+                if (coarse != nullptr) {
+                    cc[0] = ci[0] >> 2, cc[1] = ci[1] >> 2, cc[2] = ci[2] >> 2;
+                    jump = coarse[((uint32_t)cc[2] * (uint32_t)P.grid.coarse_dims[1] + (uint32_t)cc[1]) * (uint32_t)P.grid.coarse_dims[0] + (uint32_t)cc[0]] == 0;
+                }
+                F t_next;
+                bool e;
+                if (jump) {
+                    cellv[q] = 0xFFFFFFFFu; // no list to fetch
+                    F tcb[3];
+                    int bk[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        bk[k] = d[k] > 0 ? ((cc[k] + 1) << 2) : (cc[k] << 2); // the block's face the ray leaves through, as a cell boundary
+                        tcb[k] = par[k] ? Limits<F>::inf() : (P.grid.gmin[k] + (F)bk[k] * P.grid.cell[k] - o[k]) * inv[k];
+                    }
+                    const int axis = tcb[0] <= tcb[1] && tcb[0] <= tcb[2] ? 0 : (tcb[1] <= tcb[2] ? 1 : 2);
+                    t_next = axis == 0 ? tcb[0] : (axis == 1 ? tcb[1] : tcb[2]);
+                    e = t_next > t_out || t_next > best.t + slack_t;
+                    if (!e) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            if (k == axis)
+                                ci[k] = d[k] > 0 ? bk[k] : bk[k] - 1;
+                            else { // the other two stay inside the block they were in
+                                const int c = (int)((o[k] + d[k] * t_next - P.grid.gmin[k]) * P.grid.inv_cell[k]);
+                                const int lo_c = cc[k] << 2, hi_c = (cc[k] << 2) + 3 < P.grid.dims[k] - 1 ? (cc[k] << 2) + 3 : P.grid.dims[k] - 1;
+                                ci[k] = c < lo_c ? lo_c : (c > hi_c ? hi_c : c);
+                            }
+                        }
+                        e = (uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) tmax[k] = par[k] ? Limits<F>::inf() : (P.grid.gmin[k] + (F)(ci[k] + (d[k] > 0 ? 1 : 0)) * P.grid.cell[k] - o[k]) * inv[k];
+                    }
+                }
+                else {
+                    cellv[q] = ((uint32_t)ci[2] * (uint32_t)P.grid.dims[1] + (uint32_t)ci[1]) * (uint32_t)P.grid.dims[0] + (uint32_t)ci[0];
+                    const bool ax = tmax[0] <= tmax[1] && tmax[0] <= tmax[2];
+                    const bool ay = !ax && tmax[1] <= tmax[2];
+                    const bool az = !ax && !ay;
+                    t_next = ax ? tmax[0] : (ay ? tmax[1] : tmax[2]);
+                    e = t_next > t_out || t_next > best.t + slack_t;
+                    if (!e) {
+                        ci[0] += ax ? sx : 0, ci[1] += ay ? sy : 0, ci[2] += az ? sz : 0;
+                        tmax[0] += ax ? dtx : (F)0, tmax[1] += ay ? dty : (F)0, tmax[2] += az ? dtz : (F)0;
+                        e = (uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2];
+                    }
+                }
+                tnv[q] = t_next, endv[q] = e, nextv[q] = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
+                m = q + 1, stop = e;
+            }
         }
-        else if (n != 0u) {
-            R.beg0 = nr == 0 ? beg : R.beg0, R.beg1 = nr == 1 ? beg : R.beg1, R.beg2 = nr == 2 ? beg : R.beg2, R.beg3 = nr == 3 ? beg : R.beg3;
-            R.cnt |= n << (8 * nr);
-            nr += 1;
+        uint32_t hb[kWalkBatch], he[kWalkBatch];
+#pragma unroll
+        for (int q = 0; q < kWalkBatch; ++q) hb[q] = q < m && cellv[q] != 0xFFFFFFFFu ? cell_start[cellv[q]] : 0u, he[q] = q < m && cellv[q] != 0xFFFFFFFFu ? cell_start[cellv[q] + 1u] : 0u;
+#pragma unroll
+        for (int q = 0; q < kWalkBatch; ++q) {
+            if (q < m && nr < kDenseRanges) {
+                const uint32_t beg = hb[q], n = he[q] - hb[q];
+                if (n > kDenseCellMax) { // a crowded cell: its lane tests it alone, here and now
+                    for (uint32_t k = beg; k < he[q]; ++k) test_primitive<F, SO>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
+                    resolve_pending<F>(pend, a, t_min, tri_base_, best);
+                }
+                else if (n != 0u) {
+                    R.beg0 = nr == 0 ? beg : R.beg0, R.beg1 = nr == 1 ? beg : R.beg1, R.beg2 = nr == 2 ? beg : R.beg2, R.beg3 = nr == 3 ? beg : R.beg3;
+                    R.cnt |= n << (8 * nr);
+                    nr += 1;
+                }
+                t_last = tnv[q], ended = endv[q], pos = nextv[q];
+                steps_left -= 1;
+            }
         }
-        const bool ax = tmax[0] <= tmax[1] && tmax[0] <= tmax[2];
-        const bool ay = !ax && tmax[1] <= tmax[2];
-        const bool az = !ax && !ay;
-        const F t_next = ax ? tmax[0] : (ay ? tmax[1] : tmax[2]);
-        t_last = t_next;
-        if (t_next > t_out || t_next > best.t + slack_t) {
-            ended = true;
-            break;
-        }
-        ci[0] += ax ? sx : 0, ci[1] += ay ? sy : 0, ci[2] += az ? sz : 0;
-        tmax[0] += ax ? dtx : (F)0, tmax[1] += ay ? dty : (F)0, tmax[2] += az ? dtz : (F)0;
-        if ((uint32_t)ci[0] >= (uint32_t)P.grid.dims[0] || (uint32_t)ci[1] >= (uint32_t)P.grid.dims[1] || (uint32_t)ci[2] >= (uint32_t)P.grid.dims[2]) {
-            ended = true;
-            break;
-        }
+        // (the ranges filled up inside the batch: the walk takes the cells behind the last one used up again next time)
     }
+    ci[0] = (int)(pos & 1023u), ci[1] = (int)((pos >> 10) & 1023u), ci[2] = (int)(pos >> 20);
     walk_cell = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
     walk_t_out = t_out;
     return kWalkGoesOn; // ranges are out (possibly none): test them, then accel_walk_decide()
@@ -709,12 +773,12 @@ RRTX_DEV uint32_t walk_range_total(uint32_t cnt) { return (cnt & 255u) + ((cnt >
 // prepare a slice, test its entries, decide.
 template <typename F, bool SO = false, typename PP, typename HotTab, typename CellTab, typename PrimTab>
 RRTX_DEV int accel_closest_hit_batched(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
-                                       uint32_t &walk_cell, F &walk_t_out, int max_cells)
+                                       uint32_t &walk_cell, F &walk_t_out, int max_cells, const uint8_t *coarse = nullptr)
 {
     WalkRanges R;
     F t_last, slack_t;
     bool ended;
-    const int r = accel_walk_prepare<F, SO>(P, hot, cell_start, cell_prims, path, a, t_min, best, resume, walk_cell, walk_t_out, max_cells, R, t_last, slack_t, ended);
+    const int r = accel_walk_prepare<F, SO>(P, hot, cell_start, cell_prims, path, a, t_min, best, resume, walk_cell, walk_t_out, max_cells, R, t_last, slack_t, ended, coarse);
     if (r != kWalkGoesOn) return r;
     PendingRoot<F> pend = {-1, 0, 0};
     const uint32_t n = walk_range_total(R.cnt);

@@ -125,7 +125,7 @@ template <typename F> static bool make_scene(Scene<F> &s, int variant, std::mt19
     P.sph_hot = s.hot.data(), P.sph_cold = s.cold.data(), P.msph = s.ms.data(), P.tri = s.tri.data();
     P.n_sph = s.n_sph, P.n_sph_padded = s.n_pad, P.n_msph = n_ms, P.n_tri = n_tri;
     P.grid = G, P.grid_cell_start = s.cell_start.data(), P.grid_cell_prims = s.cell_prims.data(), P.grid_always = s.always.empty() ? nullptr : s.always.data();
-    P.n_always = (int)s.always.size(), P.n_grid_cells = (int)s.cell_start.size() - 1, P.n_grid_prims = (int)s.cell_start.back();
+    P.n_always = (int)s.always.size(), P.n_grid_cells = (int)s.P.grid.dims[0] * (int)s.P.grid.dims[1] * (int)s.P.grid.dims[2], P.n_grid_prims = (int)s.cell_start[(size_t)P.n_grid_cells];
     return true;
 }
 
@@ -237,8 +237,12 @@ template <typename F> static int run(const char *name, int variant, long n_rays,
         // order - here backwards -, then the decision): same answer, same slice boundaries
         HitInfo<F> b3 = {std::numeric_limits<F>::infinity(), -1};
         resume = false;
+        // (with the empty-block skipping where the grid carries the coarse occupancy bytes - built with -DRRTX_GRID_COARSE_ALWAYS=1:
+        // every grid here -, in slices of 1 .. 16 steps)
+        const uint8_t *coarse = s.P.grid.coarse_off ? (const uint8_t *)(s.cell_start.data() + s.P.grid.coarse_off) : nullptr;
+        const int batched_slice = 1 + (int)(i % 16);
         for (int guard = 0; guard < 100000; ++guard) {
-            r = accel_closest_hit_batched<F>(s.P, s.hot.data(), s.cell_start.data(), s.cell_prims.data(), path, a, t_min, b3, resume, cell, t_out, slice);
+            r = accel_closest_hit_batched<F>(s.P, s.hot.data(), s.cell_start.data(), s.cell_prims.data(), path, a, t_min, b3, resume, cell, t_out, batched_slice, coarse);
             if (r != kWalkGoesOn) break;
             resume = true;
         }

@@ -45,7 +45,7 @@ template <typename F> static int render(const rrtx_scene_desc &desc, int w, int 
         if (grid) {
             if (cell_prims.empty()) cell_prims.push_back(0);
             P.grid = G, P.grid_cell_start = cell_start.data(), P.grid_cell_prims = cell_prims.data(), P.grid_always = always.empty() ? nullptr : always.data();
-            P.n_always = (int)always.size(), P.n_grid_cells = (int)cell_start.size() - 1, P.n_grid_prims = (int)cell_start.back();
+            P.n_always = (int)always.size(), P.n_grid_cells = (int)P.grid.dims[0] * (int)P.grid.dims[1] * (int)P.grid.dims[2], P.n_grid_prims = (int)cell_start[(size_t)P.n_grid_cells];
         }
     }
     const F t_min = (F)0.001; // rrt.cpp:32 typing

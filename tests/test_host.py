@@ -194,7 +194,7 @@ def test_grid_walk_equals_the_sequential_scan_on_the_host(tmp_path):
     of 4000 gridded triangles with rays in and near the triangles' planes; the same mesh
     in fp32 must NOT get a grid (the bound admits no triangle there)."""
     exe = tmp_path / "path_host_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "path_host_check.cpp"), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DRRTX_GRID_COARSE_ALWAYS=1", os.path.join(ROOT, "tests", "path_host_check.cpp"), "-o", str(exe)], check=True)
     r = subprocess.run([str(exe), "400000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" 0 mismatches, 0 sliced-walk mismatches") == 5, r.stdout

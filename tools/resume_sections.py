@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rrt_amd
 from rrt_amd._lib import lib
 from _oracle import mesh_scene, scene_path
-NAMES = ["hand-out / polling / hand-off", "camera rays", "camera-ray lists (LIST passes)", "scan phase 1 (filter)", "scan phase 2 (exact refinement)", "shading", "sample / task bookkeeping", "grid walk (use_bvh)"]
+NAMES = ["hand-out / polling / hand-off", "camera rays", "LIST passes | dense: listing (always-list, clip, cells)", "scan phase 1 | dense: owners' exact tests", "scan phase 2 | dense: decide", "shading", "sample / task bookkeeping", "grid walk | dense: the (ray, entry) pairs"]
 f, n = mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), 48, 96)
 for name, path, W, H, spp in (("mesh", f, 600, 400, 16), ("final", scene_path("final"), 1200, 800, 48)):
     for fp64 in (False, True):
@@ -17,4 +17,10 @@ for name, path, W, H, spp in (("mesh", f, 600, 400, 16), ("final", scene_path("f
         print("%s %s: kernel %.3f ms, resume pass %.1f wave-ms in all" % (name, "f64" if fp64 else "f32", r.stats["kernel_ms"], tot / 2.4e6))
         for k in range(8):
             print("   %-34s %5.1f %%" % (NAMES[k], 100.0 * out[k] / max(1, tot)), flush=True)
+        if hasattr(lib, "rrtx_dense_diag"):
+            d = (C.c_ulonglong * 8)()
+            lib.rrtx_dense_diag(r._ctx, d)
+            it = max(1, d[0])
+            print("   dense pairing per wave-iteration: %.2f trips, %.1f pairs, %.2f candidates (largest list of a lane %.2f), %.4f lanes over the cap, %.1f walking lanes, %.1f camera-ray lanes; %d wave-iterations" % (
+                d[1] / it, d[2] / it, d[3] / it, d[4] / it, d[5] / it, d[6] / it, d[7] / it, d[0]))
         r.close()
