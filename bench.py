@@ -67,6 +67,10 @@ CLOCK_HZ = 2.4e9       # nominal; a PMC pass measures the real one (GRBM_GUI_ACT
 # against the library's symbols): the list-scan render kernel of final.txt and the accelerated one.
 LIST_KERNEL = "render_kernel<float, true, 1, false, 0, false"
 ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false"
+# the mesh sub-result: tables in HBM (ACCEL = 1), the render pass and the resume pass (RESUME = true) that finishes what it parks
+MESH_RENDER_KERNEL = "render_kernel<float, true, 0, false, 1, false, false"
+MESH_RESUME_KERNEL = "render_kernel<float, true, 0, false, 1, true, false"
+MESH = (48, 96, 600, 400, 16)  # UV sphere of 48 x 96 quads instanced three times = 27 072 triangles; frame and spp of tests/test_gpu_mesh.py and VERDICT r02
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -130,6 +134,14 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def mesh_scene_file():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mesh_gen import mesh_scene
+
+    d = tempfile.mkdtemp(prefix="rrtx_mesh_", dir="/tmp")
+    return mesh_scene(os.path.join(d, "mesh.txt"), MESH[0], MESH[1])
+
+
 def pmc_pass(counters, rrt_args, want_kernel, timeout=100):
     """One `rocprofv3 --pmc <counters>` run (no tracing) of ./rrt <rrt_args>; -> {counter: per-launch value of
     `want_kernel`, "duration_ms": ...} or None.  The program itself follows `--` (no env / shell hop)."""
@@ -189,6 +201,21 @@ def live_pmc(w, h, spp):
     g = pmc_pass(sq, base, ACCEL_KERNEL)
     if g:
         res["accelerated"] = g
+    # the mesh scene (tables in HBM): HBM traffic and VALU counters of its two passes
+    try:
+        mesh_file, _ = mesh_scene_file()
+        margs = ["-i", mesh_file, "-w", str(MESH[2]), "-h", str(MESH[3]), "-s", str(MESH[4]), "-d", str(DEPTH)]
+        mesh = {}
+        for name, kern in (("render", MESH_RENDER_KERNEL), ("resume", MESH_RESUME_KERNEL)):
+            q = pmc_pass(sq, margs, kern)
+            fr, wr = pmc_pass(["FETCH_SIZE"], margs, kern), pmc_pass(["WRITE_SIZE"], margs, kern)
+            if q and fr and wr:
+                q["hbm_read_bytes"], q["hbm_write_bytes"] = int(fr["FETCH_SIZE"] * 1024 * 2), int(wr["WRITE_SIZE"] * 1024)
+                mesh[name] = q
+        if mesh:
+            res["mesh"] = mesh
+    except Exception:
+        pass
     return res
 
 
@@ -384,6 +411,32 @@ def main():
                 del r
             configs[name] = ent
 
+        # a triangle mesh, its tables (1.4 MB of triangles, 1.3 MB of cell headers, 0.4 MB of cell lists) read from HBM / L2
+        try:
+            mesh_file, n_tri = mesh_scene_file()
+            mw, mh, ms = MESH[2], MESH[3], MESH[4]
+            ent = {"workload": "UV-sphere mesh x 3 instances = %d triangles + 101 spheres (tools/mesh_gen.py), %dx%d spp=%d d=%d fp32, use_bvh on 1 GPU" % (n_tri, mw, mh, ms, DEPTH)}
+            rm = ShardedRenderer(mesh_file, mw, mh, ms, DEPTH, fp64=False, tile_rows=args.tile_rows, device=dev, collect_stats=True, use_bvh=True)
+            secm, stm = timed(rm, 20, 2)
+            kms = stm["kernel_ms_sum"] / max(1, stm["renders"])
+            # algorithmic bytes of the walk: 8 B of list header per visited cell + (4 B index + 36 B of vertices / 16 B of sphere) per tested pair
+            logical = stm["walk_cells"] * 8 + stm["walk_pairs"] * 40
+            ent.update({"ms_per_step": round(secm / 20 * 1e3, 3), "kernel_ms": round(kms, 3), "Msamples_per_s": round(mw * mh * ms / (secm / 20) / 1e6, 1), "segments": stm["segments"], "grid_cells": stm["accel_cells"],
+                        "accel_exact": stm["accel_exact"], "cells_visited": stm["walk_cells"], "pairs_tested": stm["walk_pairs"],
+                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes": int(logical), "achieved": round(logical / (kms * 1e-3) / 1e9, 1),
+                                     "frac": round(logical / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "algorithmic bytes = cells visited x 8 B (list header) + (ray, entry) pairs tested x 40 B (index + the 9 numbers of the test), over the kernel time of the whole launch "
+                                             "(render pass + resume pass); accel_exact = 0: fp32 triangles are gridded under the approximate rule (include/rrtx.h)"}})
+            if pmc and pmc.get("mesh"):
+                tr = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in pmc["mesh"].values())
+                ent["roofline"]["traffic"] = int(tr)
+                ent["roofline"]["traffic_GBs"] = round(tr / (kms * 1e-3) / 1e9, 1)
+                ent["passes"] = {k: {"kernel_ms": round(v.get("duration_ms", 0.0), 3), "valu_issue_frac": round(valu_numbers(v)[0] / VALU_PEAK, 4), "valu_lane_utilisation": round(valu_numbers(v)[1] or 0.0, 4),
+                                     "hbm_read_bytes": v["hbm_read_bytes"], "hbm_write_bytes": v["hbm_write_bytes"]} for k, v in pmc["mesh"].items()}
+            configs["mesh"] = ent
+            del rm
+        except Exception as e:
+            configs["mesh"] = {"error": repr(e)}
         one("C2", TEST1, 1200, 800, 10, False, 20)
         one("C4", SCENE, 1200, 800, 500, True, 3)
         one("C5_on_1_gpu", SCENE, C5[0], C5[1], C5[2], False, 2)

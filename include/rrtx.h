@@ -189,6 +189,9 @@ typedef struct rrtx_stats {
     int32_t accel_exact;     /* 1: the closest hit in use is proven to equal the list scan's bit for bit (always, unless
                                 fp32 triangles were entered into the grid under the approximate rule: 0)              */
     int32_t reserved;
+    uint64_t walk_cells;     /* grid cells the walks stepped through, and ...                                              */
+    uint64_t walk_pairs;     /* ... (ray, entry) pairs they tested - counted by the densely pairing variants (scenes with
+                                triangles / moving spheres under use_bvh) only, 0 elsewhere                                */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

@@ -76,6 +76,8 @@ class Stats(C.Structure):  # rrtx_stats
         ("scanned_segments", C.c_uint64),
         ("accel_exact", C.c_int32),
         ("reserved", C.c_int32),
+        ("walk_cells", C.c_uint64),
+        ("walk_pairs", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -422,9 +422,10 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     c->use_partial = c->chunks_per_pixel > 1 || tapered_pixels > 0;
 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 256);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_counters, 256);
-    if (e == hipSuccess) e = hipMemset(c->d_counters, 0, 256);
+    // (one allocation: the launch's control words - 256 bytes - and the statistics counters behind them are cleared by ONE fill per launch)
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 512);
+    if (e == hipSuccess) c->d_counters = (unsigned long long *)(c->d_queue + 64);
+    if (e == hipSuccess) e = hipMemset(c->d_queue, 0, 512);
     if (e == hipSuccess && c->use_partial) {
         // (footprint: one vec3 per work item - 0.73 GB for 1200x800 spp 500, 6.3 GB fp32 / 12.5 GB fp64 for 3840x2160 spp 1000 at
         // 16 samples per item; several contexts on one device each hold their own)
@@ -463,7 +464,7 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat, c->d_queue, c->d_counters, c->d_partial, c->d_rows};
+    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat, c->d_queue, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (int i = 0; i < kEventRing; ++i) {
@@ -583,11 +584,11 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
         if (rc) return rc;
     }
     if (c->total_tasks == 0) return RRTX_OK;
-    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 256, st)); // task cursor, parked-item count, tail cursor, unit count; queue-over flag
+    // task cursor, parked-item count, tail cursor, unit count, queue-over flag (256 bytes) - and, behind them, the counters
 #if defined(RRTX_SECTION_DIAG) || defined(RRTX_RESUME_DIAG)
-    RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 256, st));
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 512, st));
 #else
-    if (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) RRTX_HIP(hipMemsetAsync(c->d_counters, 0, 32, st));
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) ? 256 + 48 : 256, st));
 #endif
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
@@ -672,13 +673,14 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
         if (c->p.collect_stats) {
-            unsigned long long ctr[4] = {0, 0, 0, 0};
+            unsigned long long ctr[6] = {0, 0, 0, 0, 0, 0};
             RRTX_HIP(hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));
             stats->list_mismatches = (int32_t)(ctr[2] > 0x7fffffffull ? 0x7fffffffull : ctr[2]);
             const unsigned long long seg = ctr[0];
             stats->segments = seg;
             stats->candidates = ctr[1];
             stats->scanned_segments = ctr[3];
+            stats->walk_cells = ctr[4], stats->walk_pairs = ctr[5];
             const uint64_t nprim = (uint64_t)c->n_sph + c->n_msph + c->n_tri;
             stats->prim_tests = seg * nprim;
             // B_prim = 4 scalars (sphere) / 9 scalars (moving sphere, triangle)

@@ -416,6 +416,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     bool single = false;    // RESUME: the result is the sample itself (units k >= 1), not a running sum
     const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
+    uint32_t n_walk_cells = 0, n_walk_pairs = 0; // dense variants: cells stepped through, (ray, entry) pairs tested
 #ifdef RRTX_RESUME_DIAG
     const unsigned long long resume_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -936,7 +937,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             const auto &C = *cold_params<F>(); // the grid's geometry is wanted here only
             // (tables in LDS: slices of 4 cells; the grids that ask for more, large and mostly empty, live in HBM; the macro: experiments)
             const int slice = RRTX_WALK_SLICE > 0 ? RRTX_WALK_SLICE : (ACCEL == 2 ? 4 : C.grid.walk_slice);
-            WalkRanges R = {0u, 0u, 0u, 0u, 0u};
+            WalkRanges R = {0u, 0u, 0u, 0u, 0u, 0u};
             bool is_list = false, walking = false, ended = false;
             F t_last = 0, slack_t = 0, a = 0;
             if (alive && P.max_depth <= 0) // rrt.cu:47 loop body never runs
@@ -984,6 +985,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // ---- all 64 lanes: the pairs of the wave
             RRTX_SEC(7);
             const uint32_t n_own = walk_range_total(R.cnt);
+            n_walk_cells += R.steps, n_walk_pairs += n_own;
             if (ACCEL == 2)
                 dense_candidates<F, SO, kCap>(P, hot_lds, cell_prims_lds, C.plist, path, a, R, t_min, is_list, n_own, lane, &dense_marks[wave][0], &dense_ranks[wave][0], &dense_keys[wave][0]);
             else
@@ -1051,6 +1053,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         atomicAdd(&P.counters[0], (unsigned long long)n_segments);
         atomicAdd(&P.counters[1], (unsigned long long)n_candidates);
         atomicAdd(&P.counters[3], (unsigned long long)n_scanned);
+        if (kDensePairs && n_walk_cells) atomicAdd(&P.counters[4], (unsigned long long)n_walk_cells), atomicAdd(&P.counters[5], (unsigned long long)n_walk_pairs);
     }
 #ifdef RRTX_RESUME_DIAG // developer builds (tools/resume_diag.py): the longest wave of a resume pass - iterations, clock cycles -, and the pass's totals
     if (RESUME) {

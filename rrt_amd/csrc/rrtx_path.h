@@ -590,6 +590,7 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
 struct WalkRanges {
     uint32_t beg0, beg1, beg2, beg3; // first entry of each range (an index into cell_prims)
     uint32_t cnt;                    // entries per range, 8 bits each; ranges are filled from 0 up
+    uint32_t steps;                  // cells the DDA went through for them (statistics)
 };
 constexpr uint32_t kDenseCellMax = 60;
 constexpr int kDenseRanges = 4;
@@ -597,7 +598,7 @@ template <typename F, bool SO = false, typename PP, typename HotTab, typename Ce
 RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
                                 uint32_t &walk_cell, F &walk_t_out, int max_cells, WalkRanges &R, F &t_last, F &slack_out, bool &ended, const uint8_t *coarse = nullptr)
 {
-    R.beg0 = R.beg1 = R.beg2 = R.beg3 = 0u, R.cnt = 0u;
+    R.beg0 = R.beg1 = R.beg2 = R.beg3 = 0u, R.cnt = 0u, R.steps = 0u;
     t_last = 0, slack_out = 0, ended = true;
     const F ox = path.o.x, oy = path.o.y, oz = path.o.z, dx = path.d.x, dy = path.d.y, dz = path.d.z;
     const F rx = ox - P.grid.center[0], ry = oy - P.grid.center[1], rz = oz - P.grid.center[2];
@@ -755,6 +756,7 @@ RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &c
         // (the ranges filled up inside the batch: the walk takes the cells behind the last one used up again next time)
     }
     ci[0] = (int)(pos & 1023u), ci[1] = (int)((pos >> 10) & 1023u), ci[2] = (int)(pos >> 20);
+    R.steps = (uint32_t)(max_cells - steps_left);
     walk_cell = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
     walk_t_out = t_out;
     return kWalkGoesOn; // ranges are out (possibly none): test them, then accel_walk_decide()

@@ -149,3 +149,5 @@ def test_bench_profiles_the_kernels_that_exist():
     accel = [k for k in kernels if bench.ACCEL_KERNEL in k]
     assert len(lists) == 1, lists  # the list scan has no variants by scene class
     assert len(accel) == 2 and all(k.endswith(("true>", "false>")) for k in accel), accel  # scenes of spheres alone / of every kind
+    for name in (bench.MESH_RENDER_KERNEL, bench.MESH_RESUME_KERNEL):  # the mesh sub-result's two passes: exactly one kernel each
+        assert len([k for k in kernels if name in k]) == 1, name
