@@ -221,14 +221,14 @@ def live_pmc(w, h, spp):
 
 def committed_pmc():
     """Fallback when no pass can be made here: the committed profile, only if it was measured on THIS device code."""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_live.json")
+    p = os.path.join(ROOT, "profiles", "r03_pmc_live.json")
     try:
         d = json.load(open(p))
     except Exception:
         return None
     if d.get("kernel_source_sha") != kernel_source_hash():
         return None  # stale: the kernels changed since it was taken
-    d["source"] = "profiles/r02_pmc_live.json (committed; measured on the same device code: sha %s)" % d["kernel_source_sha"]
+    d["source"] = "profiles/r03_pmc_live.json (committed; measured on the same device code: sha %s)" % d["kernel_source_sha"]
     return d
 
 

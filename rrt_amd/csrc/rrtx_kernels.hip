@@ -965,8 +965,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 else {
                     int r;
                     // (empty-space skipping - an occupancy byte per block of 4 x 4 x 4 cells, empty blocks crossed in one step: accel_walk_prepare, checked
-                    // on the host - measured on the 27 072-triangle mesh with the bytes read from HBM: 16.0 -> 20.1 ms, fp64 21.9 -> 23.9; the look-up is one
-                    // more dependent load per step and the jump costs more instructions than the 2 - 3 empty cells it saves.  Not used: EXPERIMENTS.md)
+                    // on the host - measured on the 27 072-triangle mesh: 16.0 -> 20.1 ms with the bytes read from HBM (fp64 21.9 -> 23.9), 21.7 ms from a copy
+                    // in LDS: the jump - three boundary distances, the landing cell, the DDA's state rebuilt - costs more than the 2 - 3 empty cells it
+                    // saves.  Not used: EXPERIMENTS.md)
                     const uint8_t *coarse = nullptr;
                     if (ACCEL == 2)
                         r = accel_walk_prepare<F, SO>(C, hot_lds, cell_start_lds, cell_prims_lds, path, a, t_min, best, in_walk, walk_cell, walk_t_out, slice, R, t_last, slack_t, ended, coarse);
