@@ -417,6 +417,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t n_walk_cells = 0, n_walk_pairs = 0; // dense variants: cells stepped through, (ray, entry) pairs tested
+    uint32_t walk_turns = 0;                     // dense variants: slices the current segment's walk has taken (a bound on them ends any walk: see there)
 #ifdef RRTX_RESUME_DIAG
     const unsigned long long resume_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1020,6 +1021,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             if (walking) {
                 in_walk = accel_walk_decide<F>(best, t_last, slack_t, ended) == kWalkGoesOn;
                 resolved = !in_walk;
+                // No walk may go on for ever: every slice advances at least one cell, so a walk that has taken more slices than the grid has
+                // cells along its three axes is a bug - and is ended by the reference's own scan of this segment (its answer is the answer).
+                walk_turns = in_walk ? walk_turns + 1u : 0u;
+                if (__builtin_expect(walk_turns > (uint32_t)(C.grid.dims[0] + C.grid.dims[1] + C.grid.dims[2] + 8), 0)) in_walk = false, resolved = false, need_scan = true, walk_turns = 0u;
             }
             if (VERIFY && resolved) { // test build of the kernel: lists and walks must reproduce the full sequential scan
                 const HitInfo<F> full = sequential_closest_hit<F>(P, path, a, t_min);
