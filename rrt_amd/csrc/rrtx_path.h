@@ -585,14 +585,15 @@ RRTX_DEV int accel_closest_hit(const PP &P, const HotTab &hot, const CellTab &ce
 // accel_walk_decide() whether the walk goes on.  Against accel_closest_hit() a lane may so test cells that lie
 // beyond a hit found earlier in the same slice - a superset of its tests, hence, by the order-independence above,
 // the same answer; where a slice ends the two make the same decision with the same `best`.
-// A cell of more than kDenseCellMax entries is tested here, by its lane alone (counts are packed in 8 bits).
+// A range holds up to kDenseCellMax entries (counts are packed in 8 bits); a fuller cell takes several ranges, one of more than
+// four ranges' worth is tested here, by its lane alone.
 // ---------------------------------------------------------------------------------------------
 struct WalkRanges {
     uint32_t beg0, beg1, beg2, beg3; // first entry of each range (an index into cell_prims)
     uint32_t cnt;                    // entries per range, 8 bits each; ranges are filled from 0 up
     uint32_t steps;                  // cells the DDA went through for them (statistics)
 };
-constexpr uint32_t kDenseCellMax = 60;
+constexpr uint32_t kDenseCellMax = 250; // (counts are packed in 8 bits per range)
 constexpr int kDenseRanges = 4;
 template <typename F, bool SO = false, typename PP, typename HotTab, typename CellTab, typename PrimTab>
 RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &cell_start, const PrimTab &cell_prims, const Path<F> &path, F a, F t_min, HitInfo<F> &best, bool resume,
@@ -740,14 +741,23 @@ RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &c
         for (int q = 0; q < kWalkBatch; ++q) {
             if (q < m && nr < kDenseRanges) {
                 const uint32_t beg = hb[q], n = he[q] - hb[q];
-                if (n > kDenseCellMax) { // a crowded cell: its lane tests it alone, here and now
+                if (n > kDenseCellMax * (uint32_t)kDenseRanges) { // more entries than four ranges hold: the cell's lane tests it alone, here and now
                     for (uint32_t k = beg; k < he[q]; ++k) test_primitive<F, SO>(P, hot, (int)cell_prims[k], path, a, t_min, best, pend);
                     resolve_pending<F>(pend, a, t_min, tri_base_, best);
                 }
-                else if (n != 0u) {
-                    R.beg0 = nr == 0 ? beg : R.beg0, R.beg1 = nr == 1 ? beg : R.beg1, R.beg2 = nr == 2 ? beg : R.beg2, R.beg3 = nr == 3 ? beg : R.beg3;
-                    R.cnt |= n << (8 * nr);
-                    nr += 1;
+                else if (n > kDenseCellMax * (uint32_t)(kDenseRanges - nr)) { // a crowded cell that needs more ranges than are left: it opens the next slice
+                    nr = kDenseRanges;
+                    continue;
+                }
+                else {
+                    // (a crowded cell - the pole of a UV sphere: 96 triangles meet in a point - takes several ranges of <= kDenseCellMax entries)
+                    uint32_t b = beg, left = n;
+                    while (left != 0u) {
+                        const uint32_t take = left < kDenseCellMax ? left : kDenseCellMax;
+                        R.beg0 = nr == 0 ? b : R.beg0, R.beg1 = nr == 1 ? b : R.beg1, R.beg2 = nr == 2 ? b : R.beg2, R.beg3 = nr == 3 ? b : R.beg3;
+                        R.cnt |= take << (8 * nr);
+                        nr += 1, b += take, left -= take;
+                    }
                 }
                 t_last = tnv[q], ended = endv[q], pos = nextv[q];
                 steps_left -= 1;
