@@ -173,7 +173,7 @@ template <typename F> struct ScanType<F, true> {
 #define RRTX_DENSE_WAVES 4 // ... the variants that pair (ray, entry) densely (scenes with triangles / moving spheres): their launches are bound by the latency of dependent loads, not by occupancy, and at 80 registers they spilled 60
 #endif
 #ifndef RRTX_DENSE_WAVES_F64
-#define RRTX_DENSE_WAVES_F64 2 // (fp64 mesh 600x400 spp 16: 2 / 3 / 4 waves per SIMD 19.9 / 21.9 - 23.7 / 22.7 ms; fp32: 3 / 4 / 5 / 6 -> 16.4 / 16.0 / 17.3 / 27.5)
+#define RRTX_DENSE_WAVES_F64 3 // (27 072-triangle mesh 600x400 spp 16, fp64: 2 / 3 / 4 waves per SIMD 7.7 / 6.7 / 10.5 ms; fp32: 3 / 4 / 5 -> 5.5 / 5.85 / 9.0)
 #endif
 #ifndef RRTX_ACCEL_WAVES
 #define RRTX_ACCEL_WAVES 6 // waves per SIMD the accelerated fp32 variants are compiled for (80 VGPRs: 43.6 vs 45.5 ms without the limit)
@@ -353,7 +353,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     __shared__ uint32_t cand_lds[kWavesPerBlock][kCap][64];
     // accelerated variants: the dense (ray, entry) pairing's owner marks and candidate counters (dense_candidates)
     // Measured (round 3): the dense pairing wins where a test is dear and a lane's loops are long - scenes with triangles or
-    // moving spheres: 27 072 triangles 600x400 spp 16: 20.7 -> 15.7 ms (fp64 21.5 -> 15.6), frames identical - and loses where the
+    // moving spheres: 27 072 triangles 600x400 spp 16: 20.7 -> 5.85 ms (fp64 21.5 -> 6.7), frames identical - and loses where the
     // walk was cheap to begin with: final.txt (488 spheres, tables in LDS) 37.6 -> 46.5 ms, 40 000 spheres 8.5 -> 9.4 ms - there a
     // lane's listing of its cells costs more than the per-lane walk it replaces (EXPERIMENTS.md).  So: scenes of spheres alone keep
     // the per-lane walk, everything else is paired densely.
