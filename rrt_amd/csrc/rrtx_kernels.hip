@@ -357,7 +357,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     // walk was cheap to begin with: final.txt (488 spheres, tables in LDS) 37.6 -> 46.5 ms, 40 000 spheres 8.5 -> 9.4 ms - there a
     // lane's listing of its cells costs more than the per-lane walk it replaces (EXPERIMENTS.md).  So: scenes of spheres alone keep
     // the per-lane walk, everything else is paired densely.
-    constexpr bool kDensePairs = ACCEL != 0 && !SO;
+#ifndef RRTX_DENSE_ALL
+#define RRTX_DENSE_ALL 0 // 1: scenes of spheres alone are paired densely too (experiments)
+#endif
+    constexpr bool kDensePairs = ACCEL != 0 && (!SO || RRTX_DENSE_ALL);
     constexpr int kDenseLds = kDensePairs ? 64 : 1;
     __shared__ uint32_t dense_marks[kWavesPerBlock][kDenseLds], dense_ranks[kWavesPerBlock][kDenseLds];
     __shared__ unsigned long long dense_keys[kWavesPerBlock][kDenseLds];
