@@ -666,7 +666,10 @@ RRTX_DEV int accel_walk_prepare(const PP &P, const HotTab &hot, const CellTab &c
     // walk ends there - nothing of that depends on what the cells hold), then the batch's list headers are fetched TOGETHER, then they
     // are taken up in order.  With the grid in HBM a header is a dependent load of several hundred clocks, and a walk through a large,
     // mostly empty grid (a mesh: slices of 16 cells) used to pay them one after the other.
-    constexpr int kWalkBatch = 4;
+#ifndef RRTX_WALK_BATCH
+#define RRTX_WALK_BATCH 4
+#endif
+    constexpr int kWalkBatch = RRTX_WALK_BATCH;
     int nr = 0, steps_left = max_cells;
     uint32_t pos = (uint32_t)ci[0] | ((uint32_t)ci[1] << 10) | ((uint32_t)ci[2] << 20);
     ended = false;
