@@ -75,6 +75,12 @@ template <typename F> static bool make_scene(Scene<F> &s, int variant, std::mt19
             s.tri.push_back(t);
         }
     }
+    if (variant == 3) {
+        // piles: 300 and 1 300 small spheres crowded around two points - cells of more entries than one range of the batched walk holds
+        // (kDenseCellMax: the cell takes several ranges) and than four ranges hold (its lane tests it alone)
+        for (int k = 0; k < 300; ++k) add_sphere(s, 2.3 + 0.05 * U(gen), 0.25 + 0.05 * U(gen), -1.7 + 0.05 * U(gen), 0.15 + 0.1 * U(gen));
+        for (int k = 0; k < 1300; ++k) add_sphere(s, -3.4 + 0.05 * U(gen), 0.3 + 0.05 * U(gen), 2.6 + 0.05 * U(gen), 0.15 + 0.1 * U(gen));
+    }
     if (variant == 2) {
         // a triangle mesh: a UV sphere of radius 1.2 at (0.3, 1.2, -0.4), 24 x 48 quads,
         // and a wavy sheet over a corner of the field
@@ -262,6 +268,7 @@ int main(int argc, char **argv)
     bad |= run<double>("fp64", 0, n / 2, 3);
     bad |= run<double>("fp64", 1, n / 2, 4);
     bad |= run<double>("fp64", 2, n / 2, 5); // the mesh: gridded in fp64 ...
+    bad |= run<float>("fp32", 3, n / 4, 7), bad |= run<double>("fp64", 3, n / 8, 8); // piles: crowded cells
     {
         std::mt19937_64 gen(6);
         Scene<float> s; // ... and not in fp32, where the bound admits no triangle of this size: no grid, the list is scanned

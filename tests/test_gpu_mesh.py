@@ -184,3 +184,33 @@ def test_fp32_random_meshes_through_the_verify_build(gpu, tmp_path, seed):
     o = Oracle(f, w, h, False)  # ... and the list scan's rows are the oracle's
     fo, _ = o.render(spp, 50, 1984, order=1, chunk=spp, rows=(40, 41))
     assert np.array_equal(scan[40], fo[40])
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_crowded_cells_through_the_dense_pairing(gpu, tmp_path, fp64):
+    """Piles of 300 and 1 300 small spheres around two points, in a scene with moving spheres (so that the accelerated kernel pairs
+    (ray, entry) densely): cells of more entries than one range of the batched walk holds (250: the cell takes several ranges) and
+    than four ranges hold (1 000: the cell's lane tests it alone).  Spheres and moving spheres are under the proven rule: the frame
+    must be the list scan's - the oracle's - bit for bit."""
+    rng = np.random.default_rng(21)
+    lines = ["camera 9 2.5 6 0 0.4 0 0 1 0 35 0.02 9 0.0 1.0", "material a lambertian 0.6 0.5 0.4", "material m metal 0.8 0.8 0.9 0.05", "material g dielectric 1.5", "sphere 0 -1000 0 1000 a"]
+    for i in range(-6, 6):
+        for j in range(-6, 6):
+            lines.append("sphere %r 0.2 %r 0.2 %s" % (i + 0.9 * float(rng.uniform()), j + 0.9 * float(rng.uniform()), "amg"[(i + j) % 3]))
+    for n, (cx, cy, cz) in ((300, (2.3, 0.25, -1.7)), (1300, (-3.4, 0.3, 2.6))):
+        for k in range(n):
+            lines.append("sphere %r %r %r %r %s" % (cx + 0.05 * float(rng.uniform()), cy + 0.05 * float(rng.uniform()), cz + 0.05 * float(rng.uniform()), 0.15 + 0.1 * float(rng.uniform()), "amg"[k % 3]))
+    for k in range(6):
+        x, z = float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4))
+        lines.append("msphere %r 0.3 %r %r 0.5 %r 0.0 1.0 0.25 m" % (x, z, x + 0.4, z - 0.3))
+    f = tmp_path / "piles.txt"
+    f.write_text("\n".join(lines) + "\n")
+    w, h, spp = 160, 100, 4
+    scan, s0 = _render(gpu, str(f), w, h, spp, fp64=fp64)
+    grid, s1 = _render(gpu, str(f), w, h, spp, fp64=fp64, use_bvh=True)
+    assert s1["accel_cells"] > 0 and s1["accel_exact"] == 1 and s1["walk_pairs"] > s1["segments"]  # gridded, proven rule, densely paired
+    assert np.array_equal(grid, scan) and s1["segments"] == s0["segments"]
+    _, sv = _render(gpu, str(f), w, h, 2, fp64=fp64, use_bvh=True, flags=VERIFY)
+    assert sv["list_mismatches"] == 0
+    fo, so = Oracle(str(f), w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)
+    assert np.array_equal(scan, fo) and s0["segments"] == so["segments"]
