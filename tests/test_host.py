@@ -192,12 +192,16 @@ def test_grid_walk_equals_the_sequential_scan_on_the_host(tmp_path):
     hittable_list scan on ~1.2 M rays (camera, surface, inside-sphere, lattice-aligned, grazing, far-away
     origins; coincident / nested / tiny / moving spheres, triangles), fp32 and fp64 — and in fp64 on a mesh
     of 4000 gridded triangles with rays in and near the triangles' planes; the same mesh
-    in fp32 must NOT get a grid (the bound admits no triangle there)."""
+    in fp32 must NOT get a grid (the bound admits no triangle there).  Since round 3 every ray also goes through the BATCHED walk
+    (accel_closest_hit_batched: what the densely pairing kernels run - cells listed first, entries tested afterwards in any order,
+    with the empty-block skipping on every grid: -DRRTX_GRID_COARSE_ALWAYS=1), and a fourth scene holds piles of 300 and 1 300
+    spheres in a cell or two (cells that take several ranges, cells their lane tests alone)."""
     exe = tmp_path / "path_host_check"
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DRRTX_GRID_COARSE_ALWAYS=1", os.path.join(ROOT, "tests", "path_host_check.cpp"), "-o", str(exe)], check=True)
     r = subprocess.run([str(exe), "400000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" 0 mismatches, 0 sliced-walk mismatches") == 5, r.stdout
+    assert r.stdout.count(" 0 mismatches, 0 sliced-walk mismatches, 0 batched-walk mismatches") == 7, r.stdout
+    assert "fp32 variant 3" in r.stdout and "fp64 variant 3" in r.stdout
     assert "fp64 variant 2" in r.stdout and "4 always" in r.stdout.split("fp64 variant 2")[1], r.stdout
 
 
