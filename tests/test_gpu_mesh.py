@@ -214,3 +214,41 @@ def test_crowded_cells_through_the_dense_pairing(gpu, tmp_path, fp64):
     assert sv["list_mismatches"] == 0
     fo, so = Oracle(str(f), w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)
     assert np.array_equal(scan, fo) and s0["segments"] == so["segments"]
+
+
+def test_exact_ties_through_the_dense_pairing(gpu, tmp_path):
+    """The tie rules of the sequential scan - duplicate spheres (identical t): the LATER one wins (sphere.h:46-48 accepts root ==
+    t_max); a coplanar duplicate triangle must NOT replace the earlier one (triangle.h:63 is strict); any sphere beats a triangle at
+    the same t - in a scene large enough for a grid and with triangles and moving spheres in it, so that the hits are folded by the
+    densely pairing kernel's atomic minimum (fp32: one packed 64-bit key; fp64: minimum of t, then maximum of the rank).  fp64
+    (triangles under the proven rule): the frame must be the oracle's bit for bit; fp32: the list scan's, and the grid's within the
+    stated tolerance."""
+    rng = np.random.default_rng(5)
+    lines = ["camera 0 1.5 7 0 0.3 0 0 1 0 40 0.0 7", "material first lambertian 0.9 0.1 0.1", "material second lambertian 0.1 0.9 0.1", "material third metal 0.2 0.2 0.9 0.0",
+             "material g dielectric 1.5", "sphere 0 -1000 0 1000 first"]
+    for i in range(-5, 5):
+        for j in range(-5, 5):
+            x, z, mat = i + 0.8 * float(rng.uniform()), j + 0.8 * float(rng.uniform()), ["first", "second", "third", "g"][(i + j) % 4]
+            lines.append("sphere %r 0.2 %r 0.2 %s" % (x, z, mat))
+            if (i + j) % 3 == 0:  # a duplicate of another material: the later one is what a ray sees
+                lines.append("sphere %r 0.2 %r 0.2 %s" % (x, z, "second" if mat != "second" else "third"))
+    lines += ["msphere 1.0 0.3 2.0 1.4 0.5 1.7 0.0 1.0 0.25 third", "msphere 1.0 0.3 2.0 1.4 0.5 1.7 0.0 1.0 0.25 first"]  # (camera shutter 0 - 0: both stand still, coincident)
+    # coplanar duplicate triangles low over the ground (two instances of one obj: the first instance's material must show) and a
+    # small triangle whose plane is tangent to a sphere's top (sphere and triangle report the same point at the same t)
+    lines += ["obj_beg 3 1", "obj_vtx -3 0.05 -3", "obj_vtx 3 0.05 -3", "obj_vtx 0 0.05 3", "obj_tri 0 1 2", "obj_end", "obj 0 second", "obj 0 third",
+              "sphere 2.5 0.6 0.5 0.3 first", "obj_beg 3 1", "obj_vtx 2.2 0.9 0.2", "obj_vtx 2.8 0.9 0.2", "obj_vtx 2.5 0.9 0.9", "obj_tri 0 1 2", "obj_end", "obj 1 second"]
+    f = tmp_path / "ties_dense.txt"
+    f.write_text("\n".join(lines) + "\n")
+    w, h, spp = 120, 80, 4
+    for fp64 in (True, False):
+        scan, s0 = _render(gpu, str(f), w, h, spp, fp64=fp64)
+        grid, s1 = _render(gpu, str(f), w, h, spp, fp64=fp64, use_bvh=True)
+        assert s1["accel_cells"] > 0 and s1["walk_pairs"] > 0
+        fo, so = Oracle(str(f), w, h, fp64).render(spp, 50, 1984, order=1, chunk=spp)
+        assert np.array_equal(scan, fo) and s0["segments"] == so["segments"]
+        if fp64:
+            assert s1["accel_exact"] == 1 and np.array_equal(grid, fo) and s1["segments"] == so["segments"]
+        else:
+            assert ((grid != scan).any(axis=2)).mean() <= 1e-4
+        _, sv = _render(gpu, str(f), w, h, spp, fp64=fp64, use_bvh=True, flags=VERIFY)
+        assert sv["list_mismatches"] <= (0 if fp64 else 1e-5 * sv["segments"])
