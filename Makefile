@@ -21,7 +21,7 @@ default: $(LIB) rrt rrtd
 
 all: default oracle
 
-$(CSRC)/rrtx_kernels.o: $(CSRC)/rrtx_kernels.hip $(CSRC)/rrtx_device.h $(CSRC)/rrtx_path.h $(CSRC)/rrtx_launch.h
+$(CSRC)/rrtx_kernels.o: $(CSRC)/rrtx_kernels.hip $(CSRC)/rrtx_device.h $(CSRC)/rrtx_path.h $(CSRC)/rrtx_wave.h $(CSRC)/rrtx_launch.h
 	$(HIPCC) $(KFLAGS) -c $< -o $@
 
 $(CSRC)/rrtx_api.o: $(CSRC)/rrtx_api.cpp $(CSRC)/rrtx_device.h $(CSRC)/rrtx_grid.h $(CSRC)/rrtx_pack.h $(CSRC)/rrtx_launch.h include/rrtx.h

@@ -422,6 +422,9 @@ template <typename F> RRTX_DEV void consider(F t, int idx, int tri_base, HitInfo
 // instructions) are kept out of the loops over primitives, where any one lane taking them costs the
 // whole wave — a lane holds at most one such candidate and resolves it at the end of a cell (or
 // when the next one turns up).
+#ifndef RRTX_SKIP_BEHIND
+#define RRTX_SKIP_BEHIND 1
+#endif
 template <typename F> struct PendingRoot {
     int idx; // -1: none
     F half_b, disc;
@@ -448,6 +451,12 @@ template <typename F> RRTX_DEV void sphere_unordered(F cx, F cy, F cz, F r2, con
     const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
     const F disc = half_b * half_b - a * c;
     if (disc < 0) return;
+#if RRTX_SKIP_BEHIND
+    // The sphere lies behind the origin (the ray starts outside it, c > 0, and moves away, half_b > 0): sqrt(disc) <= half_b - disc =
+    // half_b^2 - a c with a c >= 0 in floating point as in the reals, and the square root is monotone and exact on a square - so the far root
+    // (-half_b + sqrt) / a is <= 0 < t_min and the near one smaller still: the reference rejects both (sphere.h:43-48), whatever they are.
+    if (half_b > 0 && c > 0) return;
+#endif
     resolve_pending<F>(pend, a, t_min, tri_base, best); // (rare: two candidates in one cell)
     pend.idx = idx, pend.half_b = half_b, pend.disc = disc;
 }
