@@ -183,6 +183,9 @@ template <typename F> struct HitInfo {
     int idx; // unified primitive index: spheres [0,n_sph), moving [n_sph_padded, +n_msph), triangles after
 };
 
+#ifndef RRTX_SKIP_BEHIND
+#define RRTX_SKIP_BEHIND 1 // 0: experiments (A/B of the early exit for spheres behind the origin)
+#endif
 // Exact per-candidate test, reference order.  Spheres: sphere.h:33-49.
 template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, HitInfo<F> &best)
 {
@@ -191,6 +194,9 @@ template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const 
     F c = (ocx * ocx + ocy * ocy + ocz * ocz) - r2;
     F disc = half_b * half_b - a * c;
     if (disc < 0) return;
+#if RRTX_SKIP_BEHIND
+    if (half_b > 0 && c > 0) return; // behind the origin: both roots are below t_min, sphere.h:43-48 rejects them whatever they are (see sphere_unordered)
+#endif
     F sq = fsqrt(disc);
     F root = (-half_b - sq) / a;
     if (root < t_min || best.t < root) {
@@ -422,9 +428,6 @@ template <typename F> RRTX_DEV void consider(F t, int idx, int tri_base, HitInfo
 // instructions) are kept out of the loops over primitives, where any one lane taking them costs the
 // whole wave — a lane holds at most one such candidate and resolves it at the end of a cell (or
 // when the next one turns up).
-#ifndef RRTX_SKIP_BEHIND
-#define RRTX_SKIP_BEHIND 1
-#endif
 template <typename F> struct PendingRoot {
     int idx; // -1: none
     F half_b, disc;
