@@ -10,7 +10,7 @@ ARCH      ?= gfx950
 CSRC      := rrt_amd/csrc
 # -ffp-contract=off: the reference image depends on unfused fp32 rounding (DESIGN.md "Numerics").
 # -fno-slp-vectorize: keeps the primitive scan on plain v_mul/v_add (see DESIGN.md "Kernel").
-DEVFLAGS  ?= -O3 -ffp-contract=off -fno-slp-vectorize
+DEVFLAGS  ?= -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 KFLAGS    := --offload-arch=$(ARCH) $(DEVFLAGS) -fPIC -std=c++17
 HOSTFLAGS := -O2 -ffp-contract=off -fPIC -std=c++17 -Wall
 

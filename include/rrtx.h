@@ -165,6 +165,9 @@ typedef struct rrtx_params {
  * list) instead of a resume pass through the acceleration grid (A/B switch; the images are identical - the grid is
  * only used for this where it is proven to reproduce the scan bit for bit). */
 #define RRTX_FLAG_NO_TAIL_GRID 128
+/* List scan of a scene of spheres alone: keep the conservative filter on the vector unit (7 FMAs per ray and sphere)
+ * instead of the matrix cores (one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays; A/B switch, identical images). */
+#define RRTX_FLAG_SCAN_NO_MFMA 256
 
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST

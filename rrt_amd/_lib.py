@@ -197,6 +197,7 @@ _sig("rrtx_write_png", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int])
 FLAG_EXACT_SCAN = 1
 FLAG_EXACT_ACCEL = 64
 FLAG_NO_TAIL_GRID = 128
+FLAG_SCAN_NO_MFMA = 256
 
 
 class RrtxError(RuntimeError):

@@ -68,7 +68,9 @@ struct rrtx_ctx {
     void *d_hot = nullptr, *d_filter = nullptr, *d_cold = nullptr, *d_msph = nullptr, *d_tri = nullptr, *d_tri_scan = nullptr, *d_mat = nullptr;
     bool tail_ok = false;    // scene magnitudes allow the tail kernel's split scan (no NaN roots possible)
     bool use_filter = false; // conservative scan filter valid for the current scene and not disabled
-    int lds_mode = 0;        // 0 scalar loads, 1 alternate scalar / LDS, 2 LDS only
+    int lds_mode = 0;        // 0 scalar loads, 1 alternate scalar / LDS, 2 LDS only, 3 the filter on the matrix cores (f16 operands in LDS)
+    uint32_t *d_mf_table = nullptr, *d_mf_big = nullptr; // lds_mode 3: rrtx_pack.h, pack_mf_table
+    int n_mf_big = 0;
     unsigned char cam_bytes[sizeof(CameraRec<double>)];
     // work buffers
     uint32_t *d_queue = nullptr;
@@ -171,6 +173,18 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     c->lds_mode = 0;
     if (c->use_filter && hfil.size() * sizeof(SphereHot<float>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
         c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : 1; // (fp64 too: its filter is the fp32 one)
+    // scenes of spheres alone whose f16 operands fit LDS three blocks to a CU: the filter as one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays
+    if (c->lds_mode == 1 && packed.tail_ok && s->num_spheres > 0 && s->num_moving_spheres == 0 && s->num_triangles == 0 && (size_t)n_pad * 64 <= (size_t)kLdsMfBytes && !(c->p.flags & RRTX_FLAG_SCAN_NO_MFMA)) {
+        MfTable mf;
+        pack_mf_table<F>(hhot, s->num_spheres, n_pad, mf);
+        if (mf.ok) {
+            c->n_mf_big = (int)mf.big.size();
+            if (mf.big.empty()) mf.big.push_back(0); // (no empty uploads)
+            if ((rc = up((void **)&c->d_mf_table, mf.halves.data(), mf.halves.size() * 2))) return rc;
+            if ((rc = up((void **)&c->d_mf_big, mf.big.data(), mf.big.size() * 4))) return rc;
+            c->lds_mode = 3;
+        }
+    }
     if ((rc = up(&c->d_cold, hcold.data(), hcold.size() * sizeof(SphereCold<F>)))) return rc;
     if ((rc = up(&c->d_msph, hms.data(), hms.size() * sizeof(MovingSphereRec<F>)))) return rc;
     if ((rc = up(&c->d_tri, htri.data(), htri.size() * sizeof(TriangleRec<F>)))) return rc;
@@ -229,6 +243,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
     KernelParams<F> P = {};
     P.sph_hot = (const SphereHot<F> *)c->d_hot;
     P.sph_filter = (const SphereHot<float> *)c->d_filter;
+    P.mf_table = c->d_mf_table, P.mf_big = c->d_mf_big, P.n_mf_big = c->lds_mode == 3 ? c->n_mf_big : 0;
     P.sph_cold = (const SphereCold<F> *)c->d_cold;
     P.msph = (const MovingSphereRec<F> *)c->d_msph;
     P.tri = (const TriangleRec<F> *)c->d_tri;
@@ -274,7 +289,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
 void free_scene_buffers(rrtx_ctx *c)
 {
     void **bufs[] = {&c->d_hot, &c->d_filter, &c->d_cold, &c->d_msph, &c->d_tri, &c->d_tri_scan, &c->d_mat, (void **)&c->d_grid_cell_start, (void **)&c->d_grid_cell_prims,
-                     (void **)&c->d_grid_always, (void **)&c->d_plist, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
+                     (void **)&c->d_grid_always, (void **)&c->d_mf_table, (void **)&c->d_mf_big, (void **)&c->d_plist, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
     for (void **b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;

@@ -21,6 +21,7 @@ namespace rrtx {
 constexpr int kSphereUnroll = 8;  // tests per straight-line block (fp32; fp64 uses half)
 constexpr int kSpherePad = 16;    // the sphere tables are padded to a multiple of this (two blocks)
 constexpr int kLdsSceneBytes = 48 * 1024; // largest scan table mirrored in LDS
+constexpr int kLdsMfBytes = 36 * 1024;    // ... and largest table of f16 operands for the filter on the matrix cores (64 bytes per sphere: three blocks to a CU)
 #ifndef RRTX_CAND_CAP
 #define RRTX_CAND_CAP 16
 #endif
@@ -41,6 +42,8 @@ constexpr int kFilterK = 256;
 // centres are rounded to float, and the margin covers that rounding too.  Empirically false negatives
 // against the fp64 discriminant vanish at 16 here as well (tests/test_filter_bound.py).
 constexpr int kFilterK64 = 512;
+// ... and of its form on the matrix cores (f16 x 2 operands, rrtx_pack.h: pack_mf_table), twice the margin each
+constexpr int kFilterKMf = 512, kFilterKMf64 = 1024;
 // A wave of the render kernel hands its unfinished items to the tail kernel once the queue is dry and
 // at most this many of its lanes are alive (break-even of one-ray-per-wave against one-ray-per-lane).
 constexpr int kHandoffLanes = 7;
@@ -144,6 +147,9 @@ inline FastDiv make_fastdiv(uint32_t d)
 template <typename F> struct KernelParams {
     const SphereHot<F> *sph_hot;    // n_sph_padded records {cx, cy, cz, r*r}: the exact test
     const SphereHot<float> *sph_filter; // n_sph_padded records {cx, cy, cz, thr}: the conservative scan filter (fp32 for every F)
+    const uint32_t *mf_table;           // LDSMODE = 3: the filter's sphere operands for the matrix cores, n_sph_padded x 64 bytes (rrtx_pack.h, pack_mf_table)
+    const uint32_t *mf_big;             // ... and the spheres that table cannot hold (n_mf_big of them, tested exactly)
+    int32_t n_mf_big;
     const SphereCold<F> *sph_cold;
     const MovingSphereRec<F> *msph;
     const TriangleRec<F> *tri;

@@ -97,6 +97,8 @@ template <int U, bool THR_IN_VGPR> RRTX_DEV void push_if_not_less(double value, 
 #endif
 }
 
+// LDSMODE 3 (the filter on the matrix cores): slots of a lane's list of (block of 16 spheres, 16 sign bits) entries
+constexpr int kMfSlots = 8;
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
@@ -345,12 +347,12 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (sizeof(F) == 8 ? (LDSMODE == 3 ? 2 : RRTX_LIST_WAVES_F64) : 1))) render_kernel(const KernelParams<F> P)
 {
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
-    constexpr int kCap = ACCEL != 0 ? 8 : kCandCap;
-    __shared__ uint32_t cand_lds[kWavesPerBlock][kCap][64];
+    constexpr int kCap = ACCEL != 0 ? 8 : (LDSMODE == 3 && sizeof(F) == 8 ? 24 : kCandCap); // (LDSMODE 3: 2 KB of pair lists + 64 ray records)
+    __shared__ __attribute__((aligned(16))) uint32_t cand_lds[kWavesPerBlock][kCap][64];
     // accelerated variants: the dense (ray, entry) pairing's owner marks and candidate counters (dense_candidates)
     // Measured (round 3): the dense pairing wins where a test is dear and a lane's loops are long - scenes with triangles or
     // moving spheres: 27 072 triangles 600x400 spp 16: 20.7 -> 5.85 ms (fp64 21.5 -> 6.7), frames identical - and loses where the
@@ -367,12 +369,24 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     typedef typename ScanType<F, FILTER>::type ST; // precision of the scan's records: the filter is fp32 for every F
     SphereHot<ST> *const sph_lds = (SphereHot<ST> *)dyn_lds;
-    if (LDSMODE != 0) {
+    if (LDSMODE == 1 || LDSMODE == 2) {
         const SphereHot<ST> *src = ScanType<F, FILTER>::table(P);
         for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) sph_lds[i] = src[i];
         __syncthreads();
     }
+    // LDSMODE == 3: the filter on the matrix cores - the spheres' f16 operands (64 bytes each, rrtx_pack.h: pack_mf_table) in LDS, the candidate
+    // lists as 32 x 16 bits per lane (other lanes push onto them: the counters live in LDS too)
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    U4 *const mf_lds = (U4 *)dyn_lds;
+    __shared__ unsigned long long mf_keys[kWavesPerBlock][LDSMODE == 3 ? 64 : 1];
+    __shared__ uint32_t mf_ranks[kWavesPerBlock][LDSMODE == 3 && sizeof(F) == 8 ? 64 : 1];
+    if (LDSMODE == 3) {
+        const U4 *src = (const U4 *)P.mf_table;
+        for (int i = threadIdx.x; i < P.n_sph_padded * 4; i += kBlockThreads) mf_lds[i] = src[i];
+        __syncthreads();
+    }
     static_assert(ACCEL == 0 || LDSMODE == 0, "the accelerated variants scan from scalar loads");
+    static_assert(LDSMODE != 3 || (FILTER && kCap * 256 >= 2048 + 64 * 8 * (int)sizeof(F) && kCap >= 16), "the matrix-core filter's staging, pair lists and ray records live in the wave's candidate slots");
     // ACCEL == 2: [exact-test records][cell_start][cell_prims] in LDS
     SphereHot<F> *const hot_lds = (SphereHot<F> *)dyn_lds;
     uint32_t *const cell_start_lds = (uint32_t *)(hot_lds + P.n_sph_padded);
@@ -649,6 +663,199 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
         list_passes_done = list_pass ? list_passes_done + 1 : 0;
 
+        // ---------------- LDSMODE == 3: the scan of this iteration, by the whole wave --------------------------------------------
+        // The filter on the matrix cores (scenes of spheres alone; rrtx_pack.h: pack_mf_table has the operands and the bound):
+        //   f = (c.n)^2 + b.c + g - thr  as ONE dot product of 31 f16 terms,
+        // so one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays leaves the filter's VALUE in the result registers and the vector
+        // unit a compare per pair (the 7 FMAs of filter_value() are gone).  The instruction wants every lane of the wave - a lane
+        // holds one sphere's terms, one ray's terms and the results of 4 spheres x 4 OTHER lanes' rays - so the scan runs HERE,
+        // before the lanes part ways: a lane that does not scan in this iteration (not alive, no pass for it) hands in a ray
+        // nothing is a candidate for.  The lane that HOLDS a result lists the pair (ray, sphere) and later puts it to the exact
+        // test with the ray's record from LDS; hits go to the ray's owner through an LDS minimum over (t, index) - consider()'s
+        // order-free rule, as in dense_candidates().  `best` is then what the scan section further down would have found.
+        if constexpr (LDSMODE == 3) {
+        const bool scans = alive && P.max_depth > 0 && !list_pass;
+        if (__ballot(scans) != 0ull) {
+            RRTX_SEC(3);
+            typedef _Float16 H8 __attribute__((ext_vector_type(8)));
+            typedef float F4 __attribute__((ext_vector_type(4)));
+            typedef F FV4 __attribute__((ext_vector_type(4)));
+            // the wave's slice of cand_lds: [lists: 8 slots x 64 lanes x 32 bits][ray records: 64 x {o, a, d, -}], and before both the
+            // 4 KB through which the rays' operands are transposed
+            unsigned char *const area = (unsigned char *)&cand_lds[wave][0][0];
+            U4 *const stage = (U4 *)area;
+            uint32_t *const marks = (uint32_t *)area; // slot s of lane l at [s * 64 + l]: block << 16 | the signs of the lane's 16 results for it
+            FV4 *const rays = (FV4 *)(area + 2048);   // ray r at [2 r], [2 r + 1]
+            const F a = vlen2<F>(path.d); // sphere.h:36
+            best.t = Limits<F>::inf(), best.idx = -1;
+            const FilterRay fr = make_filter_ray_mf(path, a);
+            // (not sane - beyond what consider()'s order-free rule is proven for, accel_closest_hit has the same test: the lane scans by itself below, in the reference's order)
+            const bool sane = scans && fr.g < Limits<float>::inf() && a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && vlen2<F>(path.o) <= Limits<F>::coop_big();
+            // the ray's 10 numbers, scaled by a power of two that brings the largest of them under 2^14 (f16 holds 65504)
+            float lam = 1.0f;
+            {
+                const float m = fmaxf(fmaxf(ffabs(fr.g), ffabs(fr.bx)), fmaxf(ffabs(fr.by), ffabs(fr.bz)));
+                int e = 0;
+                (void)__builtin_frexpf(sane ? m : 1.0f, &e);
+                lam = __builtin_ldexpf(1.0f, e > 14 ? 14 - e : 0);
+            }
+            const float rv[10] = {fr.nx * fr.nx * lam, fr.ny * fr.ny * lam, fr.nz * fr.nz * lam, fr.nx * fr.ny * lam, fr.nx * fr.nz * lam, fr.ny * fr.nz * lam,
+                                  fr.bx * lam,         fr.by * lam,         fr.bz * lam,         fr.g * lam};
+            _Float16 hh[10], hl[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const float x = sane ? rv[q] : (q == 9 ? -60000.0f : 0.0f); // (a lane without a ray for this scan, or with one out of range: f = -60000 for every sphere, never a candidate)
+                hh[q] = (_Float16)x;
+                hl[q] = (_Float16)(x - (float)hh[q]);
+            }
+            const _Float16 ml = (_Float16)(sane ? -lam : 0.0f), z16 = (_Float16)0.0f;
+            const H8 ch0 = {hh[0], hl[0], hh[0], hh[1], hl[1], hh[1], hh[2], hl[2]};
+            const H8 ch1 = {hh[2], hh[3], hl[3], hh[3], hh[4], hl[4], hh[4], hh[5]};
+            const H8 ch2 = {hl[5], hh[5], hh[6], hl[6], hh[6], hh[7], hl[7], hh[7]};
+            const H8 ch3 = {hh[8], hl[8], hh[8], hh[9], hl[9], ml, ml, z16};
+            // transpose through LDS: the instruction wants lane l to hold terms 8 (l / 16) .. + 7 of ray 16 t + l % 16 (swizzled: no bank conflicts)
+            {
+                const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
+                stage[(uint32_t)lane * 4u + (0u ^ sw)] = __builtin_bit_cast(U4, ch0);
+                stage[(uint32_t)lane * 4u + (1u ^ sw)] = __builtin_bit_cast(U4, ch1);
+                stage[(uint32_t)lane * 4u + (2u ^ sw)] = __builtin_bit_cast(U4, ch2);
+                stage[(uint32_t)lane * 4u + (3u ^ sw)] = __builtin_bit_cast(U4, ch3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            H8 bt[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t ray = 16u * (uint32_t)t + ((uint32_t)lane & 15u);
+                bt[t] = __builtin_bit_cast(H8, stage[ray * 4u + (((uint32_t)lane >> 4) ^ ((ray >> 2) & 3u))]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // the rays' records for the exact tests, the owners' result slots
+            {
+                const FV4 r0 = {path.o.x, path.o.y, path.o.z, a}, r1 = {path.d.x, path.d.y, path.d.z, (F)0};
+                rays[2 * lane] = r0, rays[2 * lane + 1] = r1;
+                mf_keys[wave][lane] = ~0ull;
+                if (sizeof(F) == 8) mf_ranks[wave][lane] = 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t cnt = 0; // entries in this lane's list
+            // phase 2: the exact test (sphere.h:33-49) of the pairs whose filter value is not negative, each by the lane that holds the value.
+            // Bit 15 - (4 t + r) of an entry stands for the pair (ray 16 t + lane % 16, sphere block + 4 (lane / 16) + r); set = negative.
+            auto drain_mf = [&]() {
+                RRTX_SEC(4);
+                uint32_t k = 0, bits = 0, blk = 0; // (blk: the block's first sphere)
+                for (;;) { // (every lane takes every trip: the fp64 fold below is a sequence of steps the lanes take together)
+                    if (bits == 0u && k < cnt) {
+                        const uint32_t e = marks[k * 64u + (uint32_t)lane];
+                        bits = ~e & 0xFFFFu, blk = (e >> 16) << 4, k += 1;
+                    }
+                    if (__ballot(bits != 0u) == 0ull) break;
+                    const bool live = bits != 0u;
+                    const uint32_t q = live ? 15u - (uint32_t)__builtin_ctz(bits) : 0u;
+                    bits &= bits - 1u;
+                    const uint32_t owner = 16u * (q >> 2) + ((uint32_t)lane & 15u);
+                    const int idx = (int)(blk + 4u * ((uint32_t)lane >> 4) + (q & 3u));
+                    n_candidates += live ? 1u : 0u;
+                    const FV4 r0 = rays[2u * owner], r1 = rays[2u * owner + 1u];
+                    const SphereHot<F> g = P.sph_hot[live ? idx : 0];
+                    const F ra = r0.w;
+                    const F ocx = r0.x - g.cx, ocy = r0.y - g.cy, ocz = r0.z - g.cz;
+                    const F half_b = ocx * r1.x + ocy * r1.y + ocz * r1.z;
+                    const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.r2;
+                    const F disc = half_b * half_b - ra * c;
+                    bool keep = live && !(disc < 0);
+#if RRTX_SKIP_BEHIND
+                    keep = keep && !(half_b > 0 && c > 0); // (sphere_unordered has the argument)
+#endif
+                    F t_hit = 0;
+                    if (keep) { // sphere.h:41-49 without the dependence on the scan order (resolve_pending)
+                        const F sq = fsqrt(disc);
+                        t_hit = (-half_b - sq) / ra;
+                        if (t_hit < t_min) {
+                            t_hit = (-half_b + sq) / ra;
+                            keep = !(t_hit < t_min);
+                        }
+                    }
+                    if (sizeof(F) == 4) {
+                        if (keep) atomicMin(&mf_keys[wave][owner], ((unsigned long long)__float_as_uint((float)t_hit) << 32) | (unsigned long long)(~(uint32_t)idx)); // ds_min_u64: smallest t, then largest index
+                    }
+                    else {
+                        const unsigned long long tb = (unsigned long long)__double_as_longlong((double)t_hit);
+                        const unsigned long long before = mf_keys[wave][owner];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (keep) atomicMin(&mf_keys[wave][owner], tb);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        const bool wins = keep && mf_keys[wave][owner] == tb; // this pair's t is the owner's minimum so far
+                        if (wins && tb < before) mf_ranks[wave][owner] = 0u;  // ... a new one: what the slot says belongs to a larger t
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (wins) atomicMax(&mf_ranks[wave][owner], (uint32_t)idx + 1u);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                }
+                cnt = 0;
+                RRTX_SEC(3);
+            };
+            // the spheres the f16 table cannot hold (the r = 1000 ground sphere): exact, by the owner, wave-uniform index
+            {
+                const RRTX_CONST_AS uint32_t *big = (const RRTX_CONST_AS uint32_t *)P.mf_big;
+                PendingRoot<F> pend = {-1, 0, 0};
+                for (int i = 0; i < P.n_mf_big; ++i) {
+                    const int idx = (int)big[i];
+                    const SphereHot<F> g = P.sph_hot[idx];
+                    if (sane) sphere_unordered<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, idx, kNoTriangles, best, pend);
+                }
+                resolve_pending<F>(pend, a, t_min, kNoTriangles, best);
+                if (sane) n_candidates += (uint32_t)P.n_mf_big;
+            }
+            // phase 1, without a branch: the products of block b + 1 are issued before block b's results are looked at; what is looked at is
+            // their SIGN (v_alignbit shifts it into a mask, an instruction per pair).  The sums start from 2^-60 instead of 0: a sum of
+            // exactly -0 would carry the sign of a negative number without being one (sphere.h:41 reads !(disc < 0)).
+            const float tiny_c = 0x1p-60f;
+            const F4 start4 = {tiny_c, tiny_c, tiny_c, tiny_c};
+            auto signs8 = [](const F4 &x, const F4 &y) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(x[r]), 31);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(y[r]), 31);
+                return m;
+            };
+            const int last16 = n_sph_pad - 16;
+            F4 fv[4];
+            {
+                const H8 av = __builtin_bit_cast(H8, mf_lds[(uint32_t)lane]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fv[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bt[t], start4, 0, 0, 0);
+            }
+            H8 av_next = __builtin_bit_cast(H8, mf_lds[(uint32_t)(16 < last16 ? 16 : last16) * 4u + (uint32_t)lane]);
+            for (int b16 = 0; b16 < n_sph_pad; b16 += 16) {
+                F4 fn[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av_next, bt[t], start4, 0, 0, 0); // (past the end: the last block once more, nobody looks)
+                av_next = __builtin_bit_cast(H8, mf_lds[(uint32_t)(b16 + 32 < last16 ? b16 + 32 : last16) * 4u + (uint32_t)lane]);
+                const uint32_t m = (signs8(fv[0], fv[1]) << 8) | signs8(fv[2], fv[3]);
+                if (__ballot(cnt >= (uint32_t)kMfSlots) != 0ull) drain_mf();
+                if (m != 0xFFFFu) {
+                    marks[cnt * 64u + (uint32_t)lane] = ((uint32_t)b16 << 12) | m;
+                    cnt += 1;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fv[t] = fn[t];
+            }
+            drain_mf();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            {
+                const unsigned long long k = mf_keys[wave][lane];
+                if (k != ~0ull) {
+                    if (sizeof(F) == 4)
+                        consider<F>((F)__uint_as_float((uint32_t)(k >> 32)), (int)~(uint32_t)k, kNoTriangles, best);
+                    else
+                        consider<F>((F)__longlong_as_double((long long)k), (int)(mf_ranks[wave][lane] - 1u), kNoTriangles, best);
+                }
+            }
+            if (__builtin_expect(scans && !sane, 0)) best = sequential_closest_hit<F>(P, path, a, t_min); // hittable_list.h:95-117, as it stands
+            RRTX_SEC(2);
+        }
+        }
         if (alive && (!list_pass || has_list)) {
             bool done = false;
             V3<F> radiance = mk<F>(0, 0, 0);
@@ -659,7 +866,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // ---------------- closest hit: hittable_list.h:95-117 ---------------------------------
             if (!(ACCEL != 0 && in_walk)) n_segments += 1;
             const F a = vlen2<F>(path.d); // sphere.h:36
-            if (!(ACCEL != 0 && in_walk)) {
+            if (!(ACCEL != 0 && in_walk) && !(LDSMODE == 3 && !list_pass)) {
                 best.t = Limits<F>::inf();
                 best.idx = -1;
             }
@@ -762,6 +969,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             if (need_scan) {
             RRTX_SEC(3); // scan phase 1 (filter + pushes; the drains in between go to section 4)
             n_scanned += 1;
+            if constexpr (LDSMODE == 3) {
+                // (the scan has run already, by the whole wave, before the lanes parted: `best` holds its result)
+            }
+            else {
             uint32_t cnt = 0;
 
             // phase 2 body, used for flushes and at the end
@@ -903,6 +1114,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 }
             }
             drain();
+            } // LDSMODE != 3
             } // need_scan
             } // scan pass
 
@@ -1583,7 +1795,7 @@ template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
 }
 template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool filter, int lds_mode, int grid_blocks, hipStream_t stream)
 {
-    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes 1, 2 exist for the filter only: fp32 records)
     if (P.grid_cell_start) { // accelerated closest hit; the scan (scalar loads) is its fallback
         const size_t alds = accel_lds_bytes<F>(P);
         if (P.verify_lists) return launch_variant<F, true, 0, true, 1>(P, grid_blocks, 0, stream);
@@ -1594,6 +1806,7 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
     switch (lds_mode) {
     case 1: return launch_variant<F, true, 1, false, 0>(P, grid_blocks, lds, stream);
     case 2: return launch_variant<F, true, 2, false, 0>(P, grid_blocks, lds, stream);
+    case 3: return launch_variant<F, true, 3, false, 0>(P, grid_blocks, (size_t)P.n_sph_padded * 64, stream); // the filter on the matrix cores: 64 bytes of f16 operands per sphere
     default: return launch_variant<F, true, 0, false, 0>(P, grid_blocks, 0, stream);
     }
 }
@@ -1651,7 +1864,7 @@ template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const 
 }
 template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool filter, int lds_mode, int *blocks_per_cu)
 {
-    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes exist for the filter only: fp32 records)
+    const size_t lds = lds_mode ? (size_t)P.n_sph_padded * sizeof(SphereHot<float>) : 0; // (LDS modes 1, 2 exist for the filter only: fp32 records)
     if (P.grid_cell_start) {
         const size_t alds = accel_lds_bytes<F>(P);
         // (the variants for scenes of spheres alone and the densely pairing ones are compiled under different launch bounds)
@@ -1668,6 +1881,7 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     switch (lds_mode) {
     case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false, 0>, kBlockThreads, lds);
     case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false, 0>, kBlockThreads, lds);
+    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 3, false, 0>, kBlockThreads, (size_t)P.n_sph_padded * 64);
     default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 0>, kBlockThreads, 0);
     }
 }

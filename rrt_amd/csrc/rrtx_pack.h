@@ -40,6 +40,98 @@ template <typename F> void pack_unit(const F v[3], F out[3])
     out[0] = inv * v[0], out[1] = inv * v[1], out[2] = inv * v[2];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The scan filter on the matrix cores (render_kernel, LDSMODE = 3).  The filter's value
+//     f = (c.n)^2 + b.c + g - thr        (candidate <=> not f < 0; rrtx_path.h: make_filter_ray, filter_value)
+// is ONE dot product once (c.n)^2 is written out in the six monomials:  sum_{i<=j} m_ij c_i c_j . n_i n_j  (m = 1, 2), and
+// v_mfma_f32_16x16x32_f16 evaluates 16 spheres x 16 rays of it at once if every f32 operand x is split into two f16 pieces,
+// x = x_h + x_l (22 bits), and the three leading cross products x_h y_h + x_h y_l + x_l y_h are kept: 6 x 3 + 3 x 3 terms, two for
+// g (x 1), two for thr (x -1): 31 of the instruction's 32.  What is dropped (x_l y_l: 2^-22 of a term) and how the products are
+// added up (f32) is far inside the margins the filter has anyway (K eps (|o|^2 + |c|^2 + r^2), K = kFilterKMf: the numerical search of
+// tests/test_filter_bound.py finds no false negative from K = 16 up).  Spheres the f16 operands cannot hold (a monomial or the
+// threshold beyond 60000: the r = 1000 ground sphere) or resolve (r^2 < 1e-3) are listed apart (`big`) and tested exactly.
+//
+// Table: 32 halves per sphere, [block of 16 spheres][chunk of 8 terms][sphere in the block][8]: lane l of a wave reads 16 bytes at
+// (block x 64 + l) x 16 - sphere l % 16, terms 8 (l / 16) ... + 7 - the A operand of the instruction as it wants it.
+// Term order (sphere half, ray half):  q in xx yy zz xy xz yz: (Q_h, N_h) (Q_h, N_l) (Q_l, N_h);  i in x y z: (c_h, b_h) (c_h, b_l) (c_l, b_h);
+// (1, g_h) (1, g_l);  (thr_h, -1) (thr_l, -1);  (0, 0).
+// ---------------------------------------------------------------------------------------------
+inline uint16_t f32_to_f16_bits(float f) // round to nearest even; overflow -> inf; subnormals kept
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return (uint16_t)(sign | (mag > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (mag >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u); // >= 65520: rounds to inf
+    if (mag < 0x33000001u) return (uint16_t)sign;             // < 2^-25 (or == 2^-25: ties to even = 0)
+    int e = (int)(mag >> 23) - 127;
+    uint32_t m = (mag & 0x7FFFFFu) | 0x800000u; // 24 bits
+    int shift = e >= -14 ? 13 : 13 + (-14 - e); // bits to drop
+    uint32_t half = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1u))) half += 1;
+    if (e >= -14) return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (half - 0x400u))); // (a carry out of the mantissa lands in the exponent)
+    return (uint16_t)(sign | half); // subnormal (a carry makes it the smallest normal)
+}
+inline float f16_bits_to_f32(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    float out;
+    if (e == 0) {
+        out = (float)m * 0x1p-24f;
+        if (sign) out = -out;
+        return out;
+    }
+    const uint32_t x = e == 31 ? (sign | 0x7F800000u | (m << 13)) : (sign | ((e + 112u) << 23) | (m << 13));
+    memcpy(&out, &x, 4);
+    return out;
+}
+struct MfTable {
+    std::vector<uint16_t> halves; // n_pad x 32, in the layout above
+    std::vector<uint32_t> big;    // spheres the table cannot hold: tested exactly by every segment
+    bool ok = false;
+};
+template <typename F> inline void pack_mf_table(const std::vector<SphereHot<F>> &hot, int n_sph, int n_pad, MfTable &out)
+{
+    out.ok = false, out.big.clear();
+    out.halves.assign((size_t)(n_pad > 0 ? n_pad : 16) * 32, 0);
+    const long double eps = 0x1p-24L, K = sizeof(F) == 4 ? (long double)kFilterKMf : (long double)kFilterKMf64;
+    auto put = [&](int i, int term, uint16_t v) { out.halves[(((size_t)(i / 16) * 4 + (size_t)(term / 8)) * 16 + (size_t)(i % 16)) * 8 + (size_t)(term % 8)] = v; };
+    auto split = [&](long double x, uint16_t &h, uint16_t &l) {
+        h = f32_to_f16_bits((float)x);
+        l = f32_to_f16_bits((float)(x - (long double)f16_bits_to_f32(h)));
+    };
+    for (int i = 0; i < n_pad; ++i) {
+        bool in_table = i < n_sph;
+        long double v[10] = {0}, thr = 0;
+        if (in_table) {
+            const long double cx = hot[i].cx, cy = hot[i].cy, cz = hot[i].cz, r2 = hot[i].r2;
+            const long double c2 = cx * cx + cy * cy + cz * cz;
+            v[0] = cx * cx, v[1] = cy * cy, v[2] = cz * cz, v[3] = 2 * cx * cy, v[4] = 2 * cx * cz, v[5] = 2 * cy * cz, v[6] = cx, v[7] = cy, v[8] = cz;
+            // (the absolute term: what the f16 pieces lose to underflow near zero)
+            thr = (c2 - r2) - K * eps * (c2 + r2) - 1e-5L;
+            for (int k = 0; k < 9; ++k) in_table = in_table && std::isfinite((double)v[k]) && std::fabs((double)v[k]) <= 60000.0;
+            in_table = in_table && std::isfinite((double)thr) && std::fabs((double)thr) <= 60000.0 && (double)r2 >= 1e-3;
+            if (!in_table) out.big.push_back((uint32_t)i);
+        }
+        if (!in_table) { // a padding record, or a sphere listed apart: f = -60000 whatever the ray, never a candidate
+            put(i, 29, f32_to_f16_bits(60000.0f));
+            continue;
+        }
+        uint16_t h, l;
+        for (int q = 0; q < 9; ++q) {
+            split(v[q], h, l);
+            put(i, 3 * q + 0, h), put(i, 3 * q + 1, h), put(i, 3 * q + 2, l);
+        }
+        put(i, 27, f32_to_f16_bits(1.0f)), put(i, 28, f32_to_f16_bits(1.0f));
+        split(thr, h, l);
+        // (the pieces must not add up to more than thr: the lower piece is rounded to nearest - one f16 ulp of it, 2^-22 of thr, is inside the margin)
+        put(i, 29, h), put(i, 30, l);
+    }
+    out.ok = out.big.size() <= 16;
+}
+
 template <typename F> struct PackedScene {
     std::vector<MaterialRec<F>> mat;
     std::vector<SphereHot<F>> hot;        // exact-test records {c, r*r}

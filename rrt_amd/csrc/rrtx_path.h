@@ -825,7 +825,7 @@ RRTX_DEV int accel_closest_hit_batched(const PP &P, const HotTab &hot, const Cel
 struct FilterRay {
     float nx, ny, nz, bx, by, bz, g;
 };
-RRTX_DEV FilterRay make_filter_ray(const Path<float> &path, float a)
+RRTX_DEV FilterRay make_filter_ray_k(const Path<float> &path, float a, float K)
 {
     FilterRay r = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
     const float o2 = ffma(path.o.z, path.o.z, ffma(path.o.y, path.o.y, path.o.x * path.o.x));
@@ -836,11 +836,11 @@ RRTX_DEV FilterRay make_filter_ray(const Path<float> &path, float a)
         r.bx = 2.0f * ffma(-sdot, r.nx, path.o.x);
         r.by = 2.0f * ffma(-sdot, r.ny, path.o.y);
         r.bz = 2.0f * ffma(-sdot, r.nz, path.o.z);
-        r.g = ffma((float)kFilterK * 0x1p-24f, o2, ffma(sdot, sdot, -o2)); // K * unit roundoff
+        r.g = ffma(K * 0x1p-24f, o2, ffma(sdot, sdot, -o2)); // K * unit roundoff
     }
     return r;
 }
-RRTX_DEV FilterRay make_filter_ray(const Path<double> &path, double a)
+RRTX_DEV FilterRay make_filter_ray_k(const Path<double> &path, double a, float K)
 {
     FilterRay r = {0, 0, 0, 0, 0, 0, Limits<float>::inf()};
     // (decided in double: a value that overflows float must not become a finite-looking float)
@@ -854,10 +854,15 @@ RRTX_DEV FilterRay make_filter_ray(const Path<double> &path, double a)
         r.bx = 2.0f * ffma(-sdot, r.nx, ox);
         r.by = 2.0f * ffma(-sdot, r.ny, oy);
         r.bz = 2.0f * ffma(-sdot, r.nz, oz);
-        r.g = ffma((float)kFilterK64 * 0x1p-24f, o2, ffma(sdot, sdot, -o2));
+        r.g = ffma(K * 0x1p-24f, o2, ffma(sdot, sdot, -o2));
     }
     return r;
 }
+RRTX_DEV FilterRay make_filter_ray(const Path<float> &path, float a) { return make_filter_ray_k(path, a, (float)kFilterK); }
+RRTX_DEV FilterRay make_filter_ray(const Path<double> &path, double a) { return make_filter_ray_k(path, a, (float)kFilterK64); }
+// ... with the margins of the filter's form on the matrix cores (rrtx_pack.h: pack_mf_table)
+RRTX_DEV FilterRay make_filter_ray_mf(const Path<float> &path, float a) { return make_filter_ray_k(path, a, (float)kFilterKMf); }
+RRTX_DEV FilterRay make_filter_ray_mf(const Path<double> &path, double a) { return make_filter_ray_k(path, a, (float)kFilterKMf64); }
 RRTX_DEV float filter_value(const FilterRay &r, float cx, float cy, float cz)
 {
     const float uu = ffma(cz, r.nz, ffma(cy, r.ny, cx * r.nx));
