@@ -807,10 +807,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (sane) n_candidates += (uint32_t)P.n_mf_big;
             }
             // phase 1, without a branch: the products of block b + 1 are issued before block b's results are looked at; what is looked at is
-            // their SIGN (v_alignbit shifts it into a mask, an instruction per pair).  The sums start from 2^-60 instead of 0: a sum of
-            // exactly -0 would carry the sign of a negative number without being one (sphere.h:41 reads !(disc < 0)).
-            const float tiny_c = 0x1p-60f;
-            const F4 start4 = {tiny_c, tiny_c, tiny_c, tiny_c};
+            // their SIGN (v_alignbit shifts it into a mask, an instruction per pair).  A sign is a verdict because a sum is never -0 here:
+            // the three terms Q_ii,hi x N_ii,hi are squares times squares, +0 at the least, and round-to-nearest adds +0 and -0 to +0
+            // (sphere.h:41 reads !(disc < 0): -0 would be a candidate carrying the sign of none); NaN does not arise from finite f16.
+            const F4 start4 = {0.0f, 0.0f, 0.0f, 0.0f};
             auto signs8 = [](const F4 &x, const F4 &y) {
                 uint32_t m = 0;
 #pragma unroll
@@ -820,26 +820,30 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 return m;
             };
             const int last16 = n_sph_pad - 16;
-            F4 fv[4];
-            {
-                const H8 av = __builtin_bit_cast(H8, mf_lds[(uint32_t)lane]);
+            auto table_block = [&](int b) { return __builtin_bit_cast(H8, mf_lds[(uint32_t)(b < last16 ? b : last16) * 4u + (uint32_t)lane]); }; // (past the end: the last block once more, nobody looks)
+            auto products = [&](const H8 &av, F4 (&f)[4]) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fv[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bt[t], start4, 0, 0, 0);
-            }
-            H8 av_next = __builtin_bit_cast(H8, mf_lds[(uint32_t)(16 < last16 ? 16 : last16) * 4u + (uint32_t)lane]);
-            for (int b16 = 0; b16 < n_sph_pad; b16 += 16) {
-                F4 fn[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fn[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av_next, bt[t], start4, 0, 0, 0); // (past the end: the last block once more, nobody looks)
-                av_next = __builtin_bit_cast(H8, mf_lds[(uint32_t)(b16 + 32 < last16 ? b16 + 32 : last16) * 4u + (uint32_t)lane]);
-                const uint32_t m = (signs8(fv[0], fv[1]) << 8) | signs8(fv[2], fv[3]);
+                for (int t = 0; t < 4; ++t) f[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bt[t], start4, 0, 0, 0);
+            };
+            auto look = [&](const F4 (&f)[4], int b16) {
+                const uint32_t m = (signs8(f[0], f[1]) << 8) | signs8(f[2], f[3]);
                 if (__ballot(cnt >= (uint32_t)kMfSlots) != 0ull) drain_mf();
                 if (m != 0xFFFFu) {
                     marks[cnt * 64u + (uint32_t)lane] = ((uint32_t)b16 << 12) | m;
                     cnt += 1;
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fv[t] = fn[t];
+            };
+            F4 fa[4], fb[4];
+            products(table_block(0), fa);
+            H8 av_next = table_block(16);
+            for (int b16 = 0; b16 < n_sph_pad; b16 += 32) { // two blocks a trip: the results change registers, not places
+                products(av_next, fb);
+                av_next = table_block(b16 + 32);
+                look(fa, b16);
+                if (b16 + 16 >= n_sph_pad) break;
+                products(av_next, fa);
+                av_next = table_block(b16 + 48);
+                look(fb, b16 + 16);
             }
             drain_mf();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
