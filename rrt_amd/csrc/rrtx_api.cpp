@@ -174,7 +174,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (c->use_filter && hfil.size() * sizeof(SphereHot<float>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
         c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : 1; // (fp64 too: its filter is the fp32 one)
     // scenes of spheres alone whose f16 operands fit LDS three blocks to a CU: the filter as one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays
-    if (c->lds_mode == 1 && packed.tail_ok && s->num_spheres > 0 && s->num_moving_spheres == 0 && s->num_triangles == 0 && (size_t)n_pad * 64 <= (size_t)kLdsMfBytes && !(c->p.flags & RRTX_FLAG_SCAN_NO_MFMA)) {
+    if (c->lds_mode == 1 && packed.tail_ok && s->num_spheres > 0 && s->num_moving_spheres == 0 && s->num_triangles == 0 && (size_t)n_pad * 64 <= (size_t)kLdsMfBytes && !(c->p.flags & (RRTX_FLAG_SCAN_NO_MFMA | RRTX_FLAG_VERIFY_LISTS))) {
         MfTable mf;
         pack_mf_table<F>(hhot, s->num_spheres, n_pad, mf);
         if (mf.ok) {
@@ -532,7 +532,8 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     c->blocks_per_cu = bpc < 1 ? 1 : bpc;
     int64_t grid = (int64_t)c->num_cus * c->blocks_per_cu;
     const int64_t batches = ((int64_t)c->total_tasks + kTaskBatch - 1) / kTaskBatch;
-    const int64_t need_blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int wpb = (!c->accel && c->use_filter && c->lds_mode == 3) ? mf_block_threads(c->fsize) / 64 : kWavesPerBlock; // waves in a block of the render variant this scene selects
+    const int64_t need_blocks = (batches + wpb - 1) / wpb;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
@@ -560,7 +561,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (c->tail_ok && !(c->p.flags & RRTX_FLAG_NO_TAIL_KERNEL)) {
         const size_t item = c->p.fp64 ? sizeof(TailItem<double>) : sizeof(TailItem<float>);
         c->handoff_lanes = c->p.handoff_lanes > 0 ? (c->p.handoff_lanes > 64 ? 64 : c->p.handoff_lanes) : kHandoffLanes;
-        const size_t items = (size_t)c->grid_blocks * kWavesPerBlock * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
+        const size_t items = (size_t)c->grid_blocks * wpb * 128; // a wave may park all 64 lanes and up to 64 tasks of its pool
         // (tail_capacity stays 0 - no hand-off - unless all three buffers are there)
         if (int e = ensure_buffer(c, &c->d_tail_items, items * item)) return e;
         if (int e = ensure_buffer(c, &c->d_tail_rad, items * kTailSplit * 3 * c->fsize)) return e;
@@ -570,7 +571,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         const int64_t cap = (int64_t)c->num_cus * 8;
         c->tail_blocks = (int)(tb < cap ? tb : cap);
         if (c->tail_blocks < 1) c->tail_blocks = 1;
-        c->resume_blocks = c->grid_blocks; // (persistent waves pulling units: blocks beyond what is resident just find the queue empty)
+        c->resume_blocks = (c->grid_blocks * wpb + kWavesPerBlock - 1) / kWavesPerBlock; // (as many waves as the render pass had; persistent waves pulling units: blocks beyond what is resident just find the queue empty)
 #ifdef RRTX_EXPERIMENTS
         c->resume_blocks = (int)grid_knob("RRTX_RESUME_BLOCKS", (double)c->resume_blocks);
 #endif
@@ -703,7 +704,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
                                        (uint64_t)c->local_rows * c->p.image_width * 3 * c->fsize;
         }
         stats->grid_blocks = c->grid_blocks;
-        stats->block_threads = kBlockThreads;
+        stats->block_threads = (!c->accel && c->use_filter && c->lds_mode == 3) ? mf_block_threads(c->fsize) : kBlockThreads;
         stats->sample_chunk = c->chunk;
         stats->accel_cells = c->accel ? c->n_grid_cells : 0;
         stats->accel_exact = c->accel ? (c->accel_exact ? 1 : 0) : 1;

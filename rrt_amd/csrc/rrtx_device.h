@@ -31,6 +31,15 @@ constexpr int kCandCap = RRTX_CAND_CAP;      // candidate slots per lane (LDS), 
 #endif
 constexpr int kBlockThreads = RRTX_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
+// ... of the list-scan variant whose filter runs on the matrix cores: its table of f16 operands (64 bytes per sphere, one copy per
+// block in LDS) is shared by twice the waves
+#ifndef RRTX_MF_BLOCK_THREADS
+#define RRTX_MF_BLOCK_THREADS 512
+#endif
+#ifndef RRTX_MF_BLOCK_THREADS_F64
+#define RRTX_MF_BLOCK_THREADS_F64 256 // (fp64 ray records and result slots: 6.75 KB a wave, two blocks to a CU either way; six waves a block spread unevenly over the four SIMDs: 104.8 against 84.0 ms)
+#endif
+constexpr int mf_block_threads(size_t fsize) { return fsize == 4 ? RRTX_MF_BLOCK_THREADS : RRTX_MF_BLOCK_THREADS_F64; }
 constexpr uint32_t kTaskBatch = 64;    // chunk tasks a wave pulls from the global queue at a time, at most ...
 constexpr uint32_t kTaskBatchMin = 8; // ... and at least (guided: batches shrink towards the end of the chunk tasks)
 constexpr uint32_t kQueueOverFlag = 32; // P.queue[32] (its own 128-byte line): set once the cursor has passed the last task

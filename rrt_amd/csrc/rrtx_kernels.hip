@@ -347,12 +347,13 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__(kBlockThreads, (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (sizeof(F) == 8 ? (LDSMODE == 3 ? 2 : RRTX_LIST_WAVES_F64) : 1))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : 2) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
 {
+    constexpr int kBT = LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads, kWPB = kBT / 64; // threads, waves of a block of this variant
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
     constexpr int kCap = ACCEL != 0 ? 8 : (LDSMODE == 3 && sizeof(F) == 8 ? 24 : kCandCap); // (LDSMODE 3: 2 KB of pair lists + 64 ray records)
-    __shared__ __attribute__((aligned(16))) uint32_t cand_lds[kWavesPerBlock][kCap][64];
+    __shared__ __attribute__((aligned(16))) uint32_t cand_lds[kWPB][kCap][64];
     // accelerated variants: the dense (ray, entry) pairing's owner marks and candidate counters (dense_candidates)
     // Measured (round 3): the dense pairing wins where a test is dear and a lane's loops are long - scenes with triangles or
     // moving spheres: 27 072 triangles 600x400 spp 16: 20.7 -> 5.85 ms (fp64 21.5 -> 6.7), frames identical - and loses where the
@@ -364,25 +365,25 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
 #endif
     constexpr bool kDensePairs = ACCEL != 0 && (!SO || RRTX_DENSE_ALL);
     constexpr int kDenseLds = kDensePairs ? 64 : 1;
-    __shared__ uint32_t dense_marks[kWavesPerBlock][kDenseLds], dense_ranks[kWavesPerBlock][kDenseLds];
-    __shared__ unsigned long long dense_keys[kWavesPerBlock][kDenseLds];
+    __shared__ uint32_t dense_marks[kWPB][kDenseLds], dense_ranks[kWPB][kDenseLds];
+    __shared__ unsigned long long dense_keys[kWPB][kDenseLds];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[]; // LDSMODE != 0: n_sph_padded scan records; ACCEL == 2: grid
     typedef typename ScanType<F, FILTER>::type ST; // precision of the scan's records: the filter is fp32 for every F
     SphereHot<ST> *const sph_lds = (SphereHot<ST> *)dyn_lds;
     if (LDSMODE == 1 || LDSMODE == 2) {
         const SphereHot<ST> *src = ScanType<F, FILTER>::table(P);
-        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) sph_lds[i] = src[i];
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBT) sph_lds[i] = src[i];
         __syncthreads();
     }
     // LDSMODE == 3: the filter on the matrix cores - the spheres' f16 operands (64 bytes each, rrtx_pack.h: pack_mf_table) in LDS, the candidate
     // lists as 32 x 16 bits per lane (other lanes push onto them: the counters live in LDS too)
     typedef uint32_t U4 __attribute__((ext_vector_type(4)));
     U4 *const mf_lds = (U4 *)dyn_lds;
-    __shared__ unsigned long long mf_keys[kWavesPerBlock][LDSMODE == 3 ? 64 : 1];
-    __shared__ uint32_t mf_ranks[kWavesPerBlock][LDSMODE == 3 && sizeof(F) == 8 ? 64 : 1];
+    __shared__ unsigned long long mf_keys[kWPB][LDSMODE == 3 ? 64 : 1];
+    __shared__ uint32_t mf_ranks[kWPB][LDSMODE == 3 && sizeof(F) == 8 ? 64 : 1];
     if (LDSMODE == 3) {
         const U4 *src = (const U4 *)P.mf_table;
-        for (int i = threadIdx.x; i < P.n_sph_padded * 4; i += kBlockThreads) mf_lds[i] = src[i];
+        for (int i = threadIdx.x; i < P.n_sph_padded * 4; i += kBT) mf_lds[i] = src[i];
         __syncthreads();
     }
     static_assert(ACCEL == 0 || LDSMODE == 0, "the accelerated variants scan from scalar loads");
@@ -392,9 +393,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     uint32_t *const cell_start_lds = (uint32_t *)(hot_lds + P.n_sph_padded);
     GridPrim *const cell_prims_lds = (GridPrim *)(cell_start_lds + P.n_grid_cells + 1);
     if (ACCEL == 2) {
-        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBlockThreads) hot_lds[i] = P.sph_hot[i];
-        for (int i = threadIdx.x; i <= P.n_grid_cells; i += kBlockThreads) cell_start_lds[i] = P.grid_cell_start[i];
-        for (int i = threadIdx.x; i < P.n_grid_prims; i += kBlockThreads) cell_prims_lds[i] = P.grid_cell_prims[i];
+        for (int i = threadIdx.x; i < P.n_sph_padded; i += kBT) hot_lds[i] = P.sph_hot[i];
+        for (int i = threadIdx.x; i <= P.n_grid_cells; i += kBT) cell_start_lds[i] = P.grid_cell_start[i];
+        for (int i = threadIdx.x; i < P.n_grid_prims; i += kBT) cell_prims_lds[i] = P.grid_cell_prims[i];
         __syncthreads();
     }
 
@@ -416,7 +417,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     bool queue_dry = false;  // this wave's own pull came back empty
     bool queue_over = false; // the global cursor has been seen past the end
     uint32_t cursor_seen = 0, loop_count = 0;
-    const uint32_t n_waves = gridDim.x * (uint32_t)kWavesPerBlock;
+    const uint32_t n_waves = gridDim.x * (uint32_t)kWPB;
     int dry_iters = 0; // loop iterations since this wave saw the queue over
 
     // lane state
@@ -1303,7 +1304,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
 #undef RRTX_SEC
 #ifdef RRTX_DIAG
     if (lane == 0 && !RESUME) {
-        const uint32_t wid = (blockIdx.x * kBlockThreads + threadIdx.x) >> 6;
+        const uint32_t wid = (blockIdx.x * kBT + threadIdx.x) >> 6;
         unsigned long long *d = P.diag + (size_t)wid * 8;
         d[0] = diag_t0, d[1] = diag_dry, d[2] = __builtin_amdgcn_s_memrealtime(), d[3] = diag_iters, d[4] = diag_iters_dry;
         d[5] = diag_pull_t, d[6] = ((unsigned long long)diag_pulls << 32) | diag_pull_iter, d[7] = diag_pull_base;
@@ -1781,7 +1782,7 @@ template <typename F> __global__ void __launch_bounds__(256) deinterleave_kernel
 // ---------------------------------------------------------------------------------------------
 template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SO>), dim3(grid_blocks), dim3(kBlockThreads), lds_bytes, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SO>), dim3(grid_blocks), dim3(LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
 }
 // the accelerated variants (render and resume passes): tables in LDS or in HBM, scenes of spheres alone or of every kind
@@ -1885,7 +1886,7 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     switch (lds_mode) {
     case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false, 0>, kBlockThreads, lds);
     case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false, 0>, kBlockThreads, lds);
-    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 3, false, 0>, kBlockThreads, (size_t)P.n_sph_padded * 64);
+    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 3, false, 0>, mf_block_threads(sizeof(F)), (size_t)P.n_sph_padded * 64);
     default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 0>, kBlockThreads, 0);
     }
 }
