@@ -191,7 +191,8 @@ typedef struct rrtx_stats {
                                   are camera rays resolved from their pixel's candidate list)  */
     int32_t accel_exact;     /* 1: the closest hit in use is proven to equal the list scan's bit for bit (always, unless
                                 fp32 triangles were entered into the grid under the approximate rule: 0)              */
-    int32_t reserved;
+    int32_t scan_mfma;       /* 1: the list scan's filter ran on the matrix cores (scenes of spheres alone whose f16 operands fit LDS;
+                                RRTX_FLAG_SCAN_NO_MFMA keeps it on the vector unit - the images are identical)                */
     uint64_t walk_cells;     /* grid cells the walks stepped through, and ...                                              */
     uint64_t walk_pairs;     /* ... (ray, entry) pairs they tested - counted by the densely pairing variants (scenes with
                                 triangles / moving spheres under use_bvh) only, 0 elsewhere                                */

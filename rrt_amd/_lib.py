@@ -75,7 +75,7 @@ class Stats(C.Structure):  # rrtx_stats
         ("list_mismatches", C.c_int32),
         ("scanned_segments", C.c_uint64),
         ("accel_exact", C.c_int32),
-        ("reserved", C.c_int32),
+        ("scan_mfma", C.c_int32),
         ("walk_cells", C.c_uint64),
         ("walk_pairs", C.c_uint64),
     ]

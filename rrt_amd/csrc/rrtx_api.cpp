@@ -710,6 +710,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->accel_exact = c->accel ? (c->accel_exact ? 1 : 0) : 1;
         stats->local_rows = c->local_rows;
         stats->scan_filter = c->use_filter ? 1 : 0;
+        stats->scan_mfma = (!c->accel && c->use_filter && c->lds_mode == 3) ? 1 : 0;
     }
     return RRTX_OK;
 }

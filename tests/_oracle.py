@@ -290,7 +290,7 @@ def random_scene(rng, path):
     open(path, "w").write("\n".join(str(x) for x in lines) + "\n")
 
 
-def crowded_scene(rng, path):
+def crowded_scene(rng, path, spheres_only=None):
     """Random scenes with enough primitives for the acceleration grid (40 - 600): spheres over four orders of magnitude of
     size - clusters of tiny ones, a few that dwarf a cell, some far from everything -, moving spheres, and one or two small
     meshes instanced several times under random transforms (a third of the scenes: spheres alone); a camera anywhere, sometimes
@@ -298,7 +298,8 @@ def crowded_scene(rng, path):
     u = lambda lo, hi: float(rng.uniform(lo, hi))
     lines = []
     far_cam = rng.random() < 0.2
-    spheres_only = rng.random() < 0.35  # (neither moving spheres nor meshes: the kernels' variants for such scenes)
+    draw = rng.random() < 0.35
+    spheres_only = draw if spheres_only is None else spheres_only  # (neither moving spheres nor meshes: the kernels' variants for such scenes)
     span = u(2, 12)  # the crowd lives in [-span, span]^2 x [0, span / 2]
     cd = u(40, 400) if far_cam else u(0.5, 2.5) * span
     ang, el = u(0, 2 * np.pi), u(0.05, 1.2)

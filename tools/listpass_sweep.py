@@ -6,8 +6,8 @@ import rrt_amd
 from _oracle import scene_path
 W, H, spp = 1200, 800, 500
 s = rrt_amd.Scene(scene_path("final"), W, H)
-for bvh in (True, False):
-    for lp in (-1, 1, 2, 3, 4, 6):
+for bvh in (False,):
+    for lp in (-1, 1, 2, 3, 4, 6, 10):
         r = rrt_amd.Rrt(W, H, spp, 50, use_bvh=bvh, list_passes=lp); r.render(s)
         t = min((r.render(), r.stats["kernel_ms"])[1] for _ in range(3)); r.close()
         print("use_bvh %d list_passes %2d: %.3f ms" % (bvh, lp, t), flush=True)
