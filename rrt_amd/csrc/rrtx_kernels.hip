@@ -383,7 +383,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     __shared__ uint32_t mf_ranks[kWPB][LDSMODE == 3 && sizeof(F) == 8 ? 64 : 1];
     if (LDSMODE == 3) {
         const U4 *src = (const U4 *)P.mf_table;
-        for (int i = threadIdx.x; i < P.n_sph_padded * 4; i += kBT) mf_lds[i] = src[i];
+        for (int i = threadIdx.x; i < ((P.n_sph_padded + 31) & ~31) * 4; i += kBT) mf_lds[i] = src[i]; // (whole blocks of 32 spheres)
         __syncthreads();
     }
     static_assert(ACCEL == 0 || LDSMODE == 0, "the accelerated variants scan from scalar loads");
@@ -714,7 +714,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             const H8 ch1 = {hh[2], hh[3], hl[3], hh[3], hh[4], hl[4], hh[4], hh[5]};
             const H8 ch2 = {hl[5], hh[5], hh[6], hl[6], hh[6], hh[7], hl[7], hh[7]};
             const H8 ch3 = {hh[8], hl[8], hh[8], hh[9], hl[9], ml, ml, z16};
-            // transpose through LDS: the instruction wants lane l to hold terms 8 (l / 16) .. + 7 of ray 16 t + l % 16 (swizzled: no bank conflicts)
+            // transpose through LDS: the instruction wants lane l to hold terms 16 kh + 8 (l / 32) .. + 7 of ray 32 h + l % 32 (swizzled against bank conflicts)
             {
                 const uint32_t sw = ((uint32_t)lane >> 2) & 3u;
                 stage[(uint32_t)lane * 4u + (0u ^ sw)] = __builtin_bit_cast(U4, ch0);
@@ -723,12 +723,14 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 stage[(uint32_t)lane * 4u + (3u ^ sw)] = __builtin_bit_cast(U4, ch3);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            H8 bt[4];
+            H8 bt[2][2]; // [tile of 32 rays][half of the 32 terms]
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t ray = 16u * (uint32_t)t + ((uint32_t)lane & 15u);
-                bt[t] = __builtin_bit_cast(H8, stage[ray * 4u + (((uint32_t)lane >> 4) ^ ((ray >> 2) & 3u))]);
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const uint32_t ray = 32u * (uint32_t)h + ((uint32_t)lane & 31u), chunk = 2u * (uint32_t)kh + ((uint32_t)lane >> 5);
+                    bt[h][kh] = __builtin_bit_cast(H8, stage[ray * 4u + (chunk ^ ((ray >> 2) & 3u))]);
+                }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // the rays' records for the exact tests, the owners' result slots
             {
@@ -738,23 +740,27 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (sizeof(F) == 8) mf_ranks[wave][lane] = 0u;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            uint32_t cnt = 0; // entries in this lane's list
+            typedef __attribute__((address_space(3))) uint32_t *LdsWords; // (a 32-bit pointer: the list's address arithmetic stays in one register)
+            const LdsWords wp0 = (LdsWords)(marks + lane);
+            LdsWords wp = wp0; // where this lane's next entry goes: slot s at marks[s * 64 + lane]
             // phase 2: the exact test (sphere.h:33-49) of the pairs whose filter value is not negative, each by the lane that holds the value.
-            // Bit 15 - (4 t + r) of an entry stands for the pair (ray 16 t + lane % 16, sphere block + 4 (lane / 16) + r); set = negative.
+            // An entry: block << 17 | tile h << 16 | 16 signs; bit 15 - v stands for the pair (ray 32 h + lane % 32, sphere
+            // 32 block + 8 (v / 4) + 4 (lane / 32) + v % 4) - the instruction's result v of that tile; set = negative.
             auto drain_mf = [&]() {
                 RRTX_SEC(4);
-                uint32_t k = 0, bits = 0, blk = 0; // (blk: the block's first sphere)
+                const uint32_t cnt = (uint32_t)(wp - wp0) >> 6;
+                uint32_t k = 0, bits = 0, blk = 0, tile = 0; // (blk: the block's first sphere)
                 for (;;) { // (every lane takes every trip: the fp64 fold below is a sequence of steps the lanes take together)
                     if (bits == 0u && k < cnt) {
                         const uint32_t e = marks[k * 64u + (uint32_t)lane];
-                        bits = ~e & 0xFFFFu, blk = (e >> 16) << 4, k += 1;
+                        bits = ~e & 0xFFFFu, blk = (e >> 17) << 5, tile = (e >> 16) & 1u, k += 1;
                     }
                     if (__ballot(bits != 0u) == 0ull) break;
                     const bool live = bits != 0u;
                     const uint32_t q = live ? 15u - (uint32_t)__builtin_ctz(bits) : 0u;
                     bits &= bits - 1u;
-                    const uint32_t owner = 16u * (q >> 2) + ((uint32_t)lane & 15u);
-                    const int idx = (int)(blk + 4u * ((uint32_t)lane >> 4) + (q & 3u));
+                    const uint32_t owner = 32u * tile + ((uint32_t)lane & 31u);
+                    const int idx = (int)(blk + 8u * (q >> 2) + 4u * ((uint32_t)lane >> 5) + (q & 3u));
                     n_candidates += live ? 1u : 0u;
                     const FV4 r0 = rays[2u * owner], r1 = rays[2u * owner + 1u];
                     const SphereHot<F> g = P.sph_hot[live ? idx : 0];
@@ -792,7 +798,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     }
                 }
-                cnt = 0;
+                wp = wp0;
                 RRTX_SEC(3);
             };
             // the spheres the f16 table cannot hold (the r = 1000 ground sphere): exact, by the owner, wave-uniform index
@@ -807,44 +813,39 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 resolve_pending<F>(pend, a, t_min, kNoTriangles, best);
                 if (sane) n_candidates += (uint32_t)P.n_mf_big;
             }
-            // phase 1, without a branch: the products of block b + 1 are issued before block b's results are looked at; what is looked at is
-            // their SIGN (v_alignbit shifts it into a mask, an instruction per pair).  A sign is a verdict because a sum is never -0 here:
-            // the three terms Q_ii,hi x N_ii,hi are squares times squares, +0 at the least, and round-to-nearest adds +0 and -0 to +0
-            // (sphere.h:41 reads !(disc < 0): -0 would be a candidate carrying the sign of none); NaN does not arise from finite f16.
-            const F4 start4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            auto signs8 = [](const F4 &x, const F4 &y) {
-                uint32_t m = 0;
+            // phase 1, without a branch: a tile's products (32 spheres x 32 rays, two chained v_mfma_f32_32x32x16_f16) are issued before the
+            // previous tile's results are looked at; what is looked at is their SIGN (v_alignbit shifts it into a mask, an instruction
+            // per pair).  A sign is a verdict because a sum is never -0 here: the three terms Q_ii,hi x N_ii,hi are squares times squares,
+            // +0 at the least, and round-to-nearest adds +0 and -0 to +0 (sphere.h:41 reads !(disc < 0): -0 would be a candidate carrying
+            // the sign of none); NaN does not arise from finite f16.
+            typedef float F16v __attribute__((ext_vector_type(16)));
+            const F16v zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            auto signs16 = [](const F16v &x) {
+                uint32_t ma = 0, mb = 0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(x[r]), 31);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(y[r]), 31);
-                return m;
+                for (int v = 0; v < 8; ++v) ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(x[v]), 31), mb = __builtin_amdgcn_alignbit(mb, __float_as_uint(x[8 + v]), 31);
+                return (ma << 8) | mb;
             };
-            const int last16 = n_sph_pad - 16;
-            auto table_block = [&](int b) { return __builtin_bit_cast(H8, mf_lds[(uint32_t)(b < last16 ? b : last16) * 4u + (uint32_t)lane]); }; // (past the end: the last block once more, nobody looks)
-            auto products = [&](const H8 &av, F4 (&f)[4]) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) f[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bt[t], start4, 0, 0, 0);
-            };
-            auto look = [&](const F4 (&f)[4], int b16) {
-                const uint32_t m = (signs8(f[0], f[1]) << 8) | signs8(f[2], f[3]);
-                if (__ballot(cnt >= (uint32_t)kMfSlots) != 0ull) drain_mf();
+            const int n_blocks = (n_sph_pad + 31) >> 5;
+            auto table_block = [&](int b, int kh) { return __builtin_bit_cast(H8, mf_lds[(uint32_t)((b < n_blocks ? b : n_blocks - 1) * 2 + kh) * 64u + (uint32_t)lane]); }; // (past the end: the last block once more, nobody looks)
+            auto products = [&](const H8 &a0, const H8 &a1, int h) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bt[h][1], __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bt[h][0], zero16, 0, 0, 0), 0, 0, 0); };
+            auto look = [&](const F16v &f, int b, int h) {
+                const uint32_t m = signs16(f);
                 if (m != 0xFFFFu) {
-                    marks[cnt * 64u + (uint32_t)lane] = ((uint32_t)b16 << 12) | m;
-                    cnt += 1;
+                    *wp = ((uint32_t)(2 * b + h) << 16) | m;
+                    wp += 64;
                 }
             };
-            F4 fa[4], fb[4];
-            products(table_block(0), fa);
-            H8 av_next = table_block(16);
-            for (int b16 = 0; b16 < n_sph_pad; b16 += 32) { // two blocks a trip: the results change registers, not places
-                products(av_next, fb);
-                av_next = table_block(b16 + 32);
-                look(fa, b16);
-                if (b16 + 16 >= n_sph_pad) break;
-                products(av_next, fa);
-                av_next = table_block(b16 + 48);
-                look(fb, b16 + 16);
+            const LdsWords wp_full = wp0 + 64 * (kMfSlots - 2); // a block lists up to two entries a lane
+            H8 a0 = table_block(0, 0), a1 = table_block(0, 1);
+            F16v f0 = products(a0, a1, 0), f1;
+            for (int b = 0; b < n_blocks; ++b) {
+                f1 = products(a0, a1, 1);
+                a0 = table_block(b + 1, 0), a1 = table_block(b + 1, 1);
+                if (__ballot(wp > wp_full) != 0ull) drain_mf();
+                look(f0, b, 0);
+                f0 = products(a0, a1, 0);
+                look(f1, b, 1);
             }
             drain_mf();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1811,7 +1812,7 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
     switch (lds_mode) {
     case 1: return launch_variant<F, true, 1, false, 0>(P, grid_blocks, lds, stream);
     case 2: return launch_variant<F, true, 2, false, 0>(P, grid_blocks, lds, stream);
-    case 3: return launch_variant<F, true, 3, false, 0>(P, grid_blocks, (size_t)P.n_sph_padded * 64, stream); // the filter on the matrix cores: 64 bytes of f16 operands per sphere
+    case 3: return launch_variant<F, true, 3, false, 0>(P, grid_blocks, (size_t)((P.n_sph_padded + 31) & ~31) * 64, stream); // the filter on the matrix cores: 64 bytes of f16 operands per sphere
     default: return launch_variant<F, true, 0, false, 0>(P, grid_blocks, 0, stream);
     }
 }
@@ -1886,7 +1887,7 @@ template <typename F> hipError_t render_occupancy(const KernelParams<F> &P, bool
     switch (lds_mode) {
     case 1: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 1, false, 0>, kBlockThreads, lds);
     case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 2, false, 0>, kBlockThreads, lds);
-    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 3, false, 0>, mf_block_threads(sizeof(F)), (size_t)P.n_sph_padded * 64);
+    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 3, false, 0>, mf_block_threads(sizeof(F)), (size_t)((P.n_sph_padded + 31) & ~31) * 64);
     default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, render_kernel<F, true, 0, false, 0>, kBlockThreads, 0);
     }
 }

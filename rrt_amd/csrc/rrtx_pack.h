@@ -44,15 +44,16 @@ template <typename F> void pack_unit(const F v[3], F out[3])
 // The scan filter on the matrix cores (render_kernel, LDSMODE = 3).  The filter's value
 //     f = (c.n)^2 + b.c + g - thr        (candidate <=> not f < 0; rrtx_path.h: make_filter_ray, filter_value)
 // is ONE dot product once (c.n)^2 is written out in the six monomials:  sum_{i<=j} m_ij c_i c_j . n_i n_j  (m = 1, 2), and
-// v_mfma_f32_16x16x32_f16 evaluates 16 spheres x 16 rays of it at once if every f32 operand x is split into two f16 pieces,
+// the matrix cores evaluate 32 spheres x 32 rays of it at once (two chained v_mfma_f32_32x32x16_f16) if every f32 operand x is split into two f16 pieces,
 // x = x_h + x_l (22 bits), and the three leading cross products x_h y_h + x_h y_l + x_l y_h are kept: 6 x 3 + 3 x 3 terms, two for
 // g (x 1), two for thr (x -1): 31 of the instruction's 32.  What is dropped (x_l y_l: 2^-22 of a term) and how the products are
 // added up (f32) is far inside the margins the filter has anyway (K eps (|o|^2 + |c|^2 + r^2), K = kFilterKMf: the numerical search of
 // tests/test_filter_bound.py finds no false negative from K = 16 up).  Spheres the f16 operands cannot hold (a monomial or the
 // threshold beyond 60000: the r = 1000 ground sphere) or resolve (r^2 < 1e-3) are listed apart (`big`) and tested exactly.
 //
-// Table: 32 halves per sphere, [block of 16 spheres][chunk of 8 terms][sphere in the block][8]: lane l of a wave reads 16 bytes at
-// (block x 64 + l) x 16 - sphere l % 16, terms 8 (l / 16) ... + 7 - the A operand of the instruction as it wants it.
+// Table: 32 halves per sphere, [block of 32 spheres][half of the terms (16)][lane][8]: lane l of a wave reads 16 bytes at
+// ((block x 2 + half) x 64 + l) x 16 - sphere l % 32, terms 16 half + 8 (l / 32) ... + 7 - the A operand of v_mfma_f32_32x32x16_f16 as it
+// wants it; two of them, chained, cover the 32 terms.  Padded to whole blocks with records nothing is a candidate for.
 // Term order (sphere half, ray half):  q in xx yy zz xy xz yz: (Q_h, N_h) (Q_h, N_l) (Q_l, N_h);  i in x y z: (c_h, b_h) (c_h, b_l) (c_l, b_h);
 // (1, g_h) (1, g_l);  (thr_h, -1) (thr_l, -1);  (0, 0).
 // ---------------------------------------------------------------------------------------------
@@ -88,16 +89,19 @@ inline float f16_bits_to_f32(uint16_t h)
     return out;
 }
 struct MfTable {
-    std::vector<uint16_t> halves; // n_pad x 32, in the layout above
+    std::vector<uint16_t> halves; // mf_padded(n_pad) x 32, in the layout above
     std::vector<uint32_t> big;    // spheres the table cannot hold: tested exactly by every segment
     bool ok = false;
 };
-template <typename F> inline void pack_mf_table(const std::vector<SphereHot<F>> &hot, int n_sph, int n_pad, MfTable &out)
+constexpr int kMfBlock = 32; // spheres per block of the table
+inline int mf_padded(int n_pad) { return (n_pad + kMfBlock - 1) / kMfBlock * kMfBlock; }
+template <typename F> inline void pack_mf_table(const std::vector<SphereHot<F>> &hot, int n_sph, int n_pad_scan, MfTable &out)
 {
+    const int n_pad = mf_padded(n_pad_scan > 0 ? n_pad_scan : 1);
     out.ok = false, out.big.clear();
-    out.halves.assign((size_t)(n_pad > 0 ? n_pad : 16) * 32, 0);
+    out.halves.assign((size_t)n_pad * 32, 0);
     const long double eps = 0x1p-24L, K = sizeof(F) == 4 ? (long double)kFilterKMf : (long double)kFilterKMf64;
-    auto put = [&](int i, int term, uint16_t v) { out.halves[(((size_t)(i / 16) * 4 + (size_t)(term / 8)) * 16 + (size_t)(i % 16)) * 8 + (size_t)(term % 8)] = v; };
+    auto put = [&](int i, int term, uint16_t v) { out.halves[((((size_t)(i / 32) * 2 + (size_t)(term / 16)) * 64 + (size_t)(i % 32) + 32 * (size_t)((term % 16) / 8)) * 8) + (size_t)(term % 8)] = v; };
     auto split = [&](long double x, uint16_t &h, uint16_t &l) {
         h = f32_to_f16_bits((float)x);
         l = f32_to_f16_bits((float)(x - (long double)f16_bits_to_f32(h)));

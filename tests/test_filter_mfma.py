@@ -213,7 +213,7 @@ def test_host_packing_matches_the_model(tmp_path):
     out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
     n_pad, n_big, ok = (int(x) for x in out[0].split())
     T, in_table = sphere_terms(c, r2, K_MF)
-    assert n_pad == 208 and n_big == int(np.sum(~in_table)) and ok == int(n_big <= 16) and 4 <= n_big <= 16
+    assert n_pad == 224 and n_big == int(np.sum(~in_table)) and ok == int(n_big <= 16) and 4 <= n_big <= 16
     assert not in_table[0] and in_table[1] and not in_table[2] and not in_table[3] and not in_table[4]
     for i in range(n_pad):
         f = out[1 + i].split()
