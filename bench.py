@@ -24,12 +24,15 @@ Workloads (BASELINE.json `configs`):
 The image is bit-identical for every N and tile size (tests/test_gpu_configs.py, tests/test_gpu_group.py).
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields:
-  roofline     - for the dominant kernel, against the unit that BINDS it.  There is no dense contraction on this path
-                 (no MFMA) and the scene is 7.8 KB (no HBM stream): the kernel is bound by VALU issue.  `achieved` =
-                 VALU wave-instructions per clock per SIMD, `peak` = 0.5 (one wave-instruction every second clock:
-                 157.3 TFLOP/s fp32 = 256 CUs x 4 SIMDs x 32 FMA lanes x 2.4 GHz), `frac` = achieved / peak <= 1.
+  roofline     - for the dominant kernel, against the unit that BINDS it.  The scene is 7.8 KB (no HBM stream); the scan's
+                 filter is a dot product of 31 f16 terms per (ray, sphere) and runs on the matrix cores (two chained
+                 v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays), everything else - camera rays, exact tests, shading - on
+                 the vector unit, and both are issued through the SIMD's one vector port: `achieved` = wave-instructions per
+                 clock per SIMD with a matrix instruction counted as the 4 it keeps out (8 clocks), `peak` = 0.5 (one
+                 wave-instruction every second clock), `frac` = achieved / peak <= 1.  `roofline.mfma` prices the matrix
+                 instructions alone against the dense f16 peak (2.5 PFLOP/s): the filter is a third of the kernel's cycles.
                  At N = 1 the counters come from rocprofv3 --pmc passes THIS run makes (SQ_INSTS_VALU & co. in one
-                 pass, FETCH_SIZE and WRITE_SIZE in passes of their own - the HBM `traffic`), on the `rrt` binary
+                 pass, the matrix pipe's in another, FETCH_SIZE and WRITE_SIZE in passes of their own - the HBM `traffic`), on the `rrt` binary
                  rendering the same workload through the same library, before this process touches the GPU.
                  `logical_hbm` keeps SURVEY.md 8(d)'s figure - algorithmic bytes of the reference's list scan / kernel
                  time against 8 TB/s - as a named field: it exceeds 1 by construction (one 16-byte record read serves
@@ -60,12 +63,16 @@ C3 = (1200, 800, 500)
 C5 = (3840, 2160, 1000)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK = 0.5        # VALU wave-instructions per clock per SIMD: a wave64 instruction occupies the 32-lane fp32 pipe for 2 clocks
+MFMA_ISSUE = 4         # ... and a matrix instruction holds that issue port for 8 clocks (MI355X_MICROARCH.md, cycle constants): 4 plain instructions' worth
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16 (MI355X_MICROARCH.md)
+MFMA_FLOP = 2 * 32 * 32 * 16  # per v_mfma_f32_32x32x16_f16
+MF_BLOCK = 32          # spheres per block of the filter's table (rrtx_pack.h: kMfBlock)
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9       # nominal; a PMC pass measures the real one (GRBM_GUI_ACTIVE / 8 XCDs / duration)
 # Names as rocprofv3 prints them, up to and including the RESUME = false argument - prefixes, so that template
 # parameters added behind it (SO: scenes of spheres alone) do not lose the match (tests/test_cabi.py checks both
 # against the library's symbols): the list-scan render kernel of final.txt and the accelerated one.
-LIST_KERNEL = "render_kernel<float, true, 1, false, 0, false"
+LIST_KERNEL = "render_kernel<float, true, 3, false, 0, false"
 ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false"
 # the mesh sub-result: tables in HBM (ACCEL = 1), the render pass and the resume pass (RESUME = true) that finishes what it parks
 MESH_RENDER_KERNEL = "render_kernel<float, true, 0, false, 1, false, false"
@@ -186,12 +193,16 @@ def live_pmc(w, h, spp):
     """The passes behind roofline.frac and roofline.traffic (list scan) and the accelerated kernel's lane utilisation."""
     base = ["-i", SCENE, "-w", str(w), "-h", str(h), "-s", str(spp), "-d", str(DEPTH)]
     sq = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    mf = ["SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16", "GRBM_GUI_ACTIVE"]  # the matrix pipe, a pass of its own
     res = {"source": "rocprofv3 --pmc passes made by this bench.py run on `rrt` (same library, same workload), one counter group per pass, no tracing",
            "kernel_source_sha": kernel_source_hash()}
     a = pmc_pass(sq, base + ["-b"], LIST_KERNEL)
     if not a:
         return None
     res["list_scan"] = a
+    m = pmc_pass(mf, base + ["-b"], LIST_KERNEL)
+    if m:
+        res["list_scan_mfma"] = {k: v for k, v in m.items() if k != "kernel_name"}
     f = pmc_pass(["FETCH_SIZE"], base + ["-b"], LIST_KERNEL)
     wv = pmc_pass(["WRITE_SIZE"], base + ["-b"], LIST_KERNEL)
     if f and wv:
@@ -541,28 +552,42 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         logical = total_bytes / (kernel_ms * 1e-3) / 1e9 / world  # GB/s per GPU
 
-        # ---- the binding unit: VALU issue
+        # ---- the binding unit: the vector issue port, which the matrix instructions of the scan's filter share with everything else
         clock = CLOCK_HZ
-        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD", "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL + ", ...>", "kernel_ms": round(kernel_ms, 3)}
+        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD (a matrix instruction = %d)" % MFMA_ISSUE, "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL + ", ...>", "kernel_ms": round(kernel_ms, 3)}
+        # what the run can count itself: the filter's matrix instructions - per scanned wave-segment (>= scanned segments / 64) and block of 32
+        # spheres, 2 tiles of 32 rays x 2 halves of the 32 terms
+        n_blocks = (488 + MF_BLOCK - 1) // MF_BLOCK
+        mfma_min = scanned / world / 64.0 * n_blocks * 4
         if pmc and pmc.get("list_scan"):
             per_clk, lanes, ghz = valu_numbers(pmc["list_scan"])
             if ghz:
                 clock = ghz * 1e9
             if pmc["list_scan"].get("kernel_name"):
                 roof["kernel"] = pmc["list_scan"]["kernel_name"].split("(")[0].replace("void ", "")
+            cyc = pmc["list_scan"]["GRBM_GUI_ACTIVE"] / 8.0
+            mm = pmc.get("list_scan_mfma") or {}
+            n_mfma = mm.get("SQ_INSTS_MFMA")
+            if n_mfma is not None:  # SQ_INSTS_VALU counts a matrix instruction once: weigh it by the issue clocks it holds
+                per_clk = (pmc["list_scan"]["SQ_INSTS_VALU"] + (MFMA_ISSUE - 1) * n_mfma) / (N_SIMD * cyc)
             roof.update({"achieved": round(per_clk, 4), "frac": round(per_clk / VALU_PEAK, 4), "valu_lane_utilisation": round(lanes, 4) if lanes else None,
                          "shader_clock_GHz": round(ghz, 3) if ghz else None, "counters": {k: v for k, v in pmc["list_scan"].items() if k != "kernel_name"}, "source": pmc["source"], "kernel_source_sha": pmc.get("kernel_source_sha")})
+            if n_mfma is not None:
+                mcyc = mm["GRBM_GUI_ACTIVE"] / 8.0
+                tf = n_mfma * MFMA_FLOP / (mm.get("duration_ms", kernel_ms) * 1e-3) / 1e12
+                roof["mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS, "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "instructions": int(n_mfma),
+                                "pipe_busy_frac": round(mm["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * mcyc), 4) if mm.get("SQ_VALU_MFMA_BUSY_CYCLES") else None, "counters": mm,
+                                "note": "v_mfma_f32_32x32x16_f16 of the scan filter (phase 1: a third of the kernel's cycles; the rest of a path tracer's loop - camera rays, exact tests, shading - has no matrix form); "
+                                        "instructions x %d flop / kernel time against the dense f16 peak" % MFMA_FLOP}
             roof["traffic"] = (pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) if "hbm_read_bytes" in pmc else None
             if "hbm_read_bytes" in pmc:
                 roof["traffic_detail"] = {"read_bytes": pmc["hbm_read_bytes"], "write_bytes": pmc["hbm_write_bytes"], "hbm_GBs": round((pmc["hbm_read_bytes"] + pmc["hbm_write_bytes"]) / (kernel_ms * 1e-3) / 1e9, 1),
                                           "note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, separate passes; per launch"}
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None, "source": "no PMC pass possible in this run and no committed profile of this device code"})
-        # the part of it the run can count itself: the scan filter's 8 VALU instructions per executed (ray, sphere) test
-        tests_executed = scanned / world * 488  # per GPU (wave-level: one test = 8 wave-instructions for 64 rays)
-        filt = tests_executed * 8 / 64 / (kernel_ms * 1e-3 * N_SIMD * clock)
-        roof["filter_only"] = {"achieved": round(filt, 4), "frac": round(filt / VALU_PEAK, 4),
-                               "note": "lower bound counted by the kernel itself: 8 VALU instructions per executed (ray, sphere) filter test x scanned segments x 488 / 64 lanes, over kernel time x 1024 SIMDs x clock"}
+        filt = mfma_min * MFMA_ISSUE / (kernel_ms * 1e-3 * N_SIMD * clock)
+        roof["filter_only"] = {"achieved": round(filt, 4), "frac": round(filt / VALU_PEAK, 4), "mfma_instructions_min": int(mfma_min), "mfma_TFLOPs_min": round(mfma_min * MFMA_FLOP / (kernel_ms * 1e-3) / 1e12, 1),
+                               "note": "lower bound counted by the kernel itself: scanned segments / 64 lanes x %d blocks of 32 spheres x 4 matrix instructions (x %d issue slots each), over kernel time x 1024 SIMDs x clock" % (n_blocks, MFMA_ISSUE)}
         if roof.get("frac") is None:
             roof["achieved"], roof["frac"] = roof["filter_only"]["achieved"], roof["filter_only"]["frac"]
             roof["source"] += "; achieved / frac = the filter-only lower bound"
