@@ -37,7 +37,7 @@ constexpr int kWavesPerBlock = kBlockThreads / 64;
 #define RRTX_MF_BLOCK_THREADS 512
 #endif
 #ifndef RRTX_MF_BLOCK_THREADS_F64
-#define RRTX_MF_BLOCK_THREADS_F64 256 // (fp64 ray records and result slots: 6.75 KB a wave, two blocks to a CU either way; six waves a block spread unevenly over the four SIMDs: 104.8 against 84.0 ms)
+#define RRTX_MF_BLOCK_THREADS_F64 768 // (fp64 ray records and result slots: 6.75 KB a wave - ONE block of twelve waves to a CU, three to a SIMD: 66.5 ms; 256 threads, two blocks = 2 waves per SIMD: 79.2; 384, six waves spread unevenly over the four SIMDs: 104.8)
 #endif
 constexpr int mf_block_threads(size_t fsize) { return fsize == 4 ? RRTX_MF_BLOCK_THREADS : RRTX_MF_BLOCK_THREADS_F64; }
 constexpr uint32_t kTaskBatch = 64;    // chunk tasks a wave pulls from the global queue at a time, at most ...

@@ -162,6 +162,9 @@ template <typename F> struct ScanType<F, true> {
 #ifndef RRTX_LIST_WAVES_F64
 #define RRTX_LIST_WAVES_F64 5 // waves per SIMD the fp64 list-scan variants are compiled for (94 VGPRs, 12 spilled: 92.4 vs 102.0 ms; 6: 100.1)
 #endif
+#ifndef RRTX_MF_WAVES_F64
+#define RRTX_MF_WAVES_F64 (RRTX_MF_BLOCK_THREADS_F64 == 768 ? 3 : 2) // waves per SIMD the fp64 matrix-core scan is compiled for: what its LDS lets be resident
+#endif
 #ifndef RRTX_ACCEL_WAVES_F64
 #define RRTX_ACCEL_WAVES_F64 4 // ... and the fp64 ones (127 VGPRs: 66.9 vs 72.5 ms at spp 504; the fp64 list scan takes 128.2)
 #endif
@@ -347,7 +350,7 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : 2) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : RRTX_MF_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
 {
     constexpr int kBT = LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads, kWPB = kBT / 64; // threads, waves of a block of this variant
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred

@@ -35,7 +35,7 @@ def test_final_scene_matches_the_oracle_on_the_matrix_cores(gpu, fp64):
     want, so = Oracle(f, w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
     mf, vu = render_both(gpu, f, w, h, spp, 50, fp64)
     assert mf[1]["scan_mfma"] == 1 and vu[1]["scan_mfma"] == 0 and mf[1]["scan_filter"] == 1
-    assert mf[1]["block_threads"] == (256 if fp64 else 512)
+    assert mf[1]["block_threads"] == (768 if fp64 else 512)
     assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want)
     assert mf[1]["segments"] == so["segments"] == vu[1]["segments"]
     # the filter lets through what the exact test then rejects: a few percent more than the 7-FMA filter does
