@@ -99,6 +99,10 @@ template <int U, bool THR_IN_VGPR> RRTX_DEV void push_if_not_less(double value, 
 
 // LDSMODE 3 (the filter on the matrix cores): slots of a lane's list of (block of 16 spheres, 16 sign bits) entries
 constexpr int kMfSlots = 8;
+#ifndef RRTX_MF_BALANCE
+#define RRTX_MF_BALANCE 1 // the pairs the filter lets through are shared out evenly over the wave's lanes before the exact test
+#endif
+constexpr int kMfQueue = 256; // ... through a queue of this many pairs (more than that: every lane tests what it listed)
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +388,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     U4 *const mf_lds = (U4 *)dyn_lds;
     __shared__ unsigned long long mf_keys[kWPB][LDSMODE == 3 ? 64 : 1];
     __shared__ uint32_t mf_ranks[kWPB][LDSMODE == 3 && sizeof(F) == 8 ? 64 : 1];
+    __shared__ uint16_t mf_queue[kWPB][LDSMODE == 3 && RRTX_MF_BALANCE ? kMfQueue : 1]; // (ray, sphere) pairs on their way to the exact test
     if (LDSMODE == 3) {
         const U4 *src = (const U4 *)P.mf_table;
         for (int i = threadIdx.x; i < ((P.n_sph_padded + 31) & ~31) * 4; i += kBT) mf_lds[i] = src[i]; // (whole blocks of 32 spheres)
@@ -749,11 +754,48 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // phase 2: the exact test (sphere.h:33-49) of the pairs whose filter value is not negative, each by the lane that holds the value.
             // An entry: block << 17 | tile h << 16 | 16 signs; bit 15 - v stands for the pair (ray 32 h + lane % 32, sphere
             // 32 block + 8 (v / 4) + 4 (lane / 32) + v % 4) - the instruction's result v of that tile; set = negative.
-            auto drain_mf = [&]() {
-                RRTX_SEC(4);
-                const uint32_t cnt = (uint32_t)(wp - wp0) >> 6;
+            // One pair to the exact test, its hit to the ray's owner: LDS minimum over (t, index) - consider()'s rule, as in dense_candidates()
+            auto test_pair = [&](bool live, uint32_t owner, int idx) {
+                const FV4 r0 = rays[2u * owner], r1 = rays[2u * owner + 1u];
+                const SphereHot<F> g = P.sph_hot[live ? idx : 0];
+                const F ra = r0.w;
+                const F ocx = r0.x - g.cx, ocy = r0.y - g.cy, ocz = r0.z - g.cz;
+                const F half_b = ocx * r1.x + ocy * r1.y + ocz * r1.z;
+                const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.r2;
+                const F disc = half_b * half_b - ra * c;
+                bool keep = live && !(disc < 0);
+#if RRTX_SKIP_BEHIND
+                keep = keep && !(half_b > 0 && c > 0); // (sphere_unordered has the argument)
+#endif
+                F t_hit = 0;
+                if (keep) { // sphere.h:41-49 without the dependence on the scan order (resolve_pending)
+                    const F sq = fsqrt(disc);
+                    t_hit = (-half_b - sq) / ra;
+                    if (t_hit < t_min) {
+                        t_hit = (-half_b + sq) / ra;
+                        keep = !(t_hit < t_min);
+                    }
+                }
+                if (sizeof(F) == 4) {
+                    if (keep) atomicMin(&mf_keys[wave][owner], ((unsigned long long)__float_as_uint((float)t_hit) << 32) | (unsigned long long)(~(uint32_t)idx)); // ds_min_u64: smallest t, then largest index
+                }
+                else { // (a sequence of steps the lanes take together)
+                    const unsigned long long tb = (unsigned long long)__double_as_longlong((double)t_hit);
+                    const unsigned long long before = mf_keys[wave][owner];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (keep) atomicMin(&mf_keys[wave][owner], tb);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const bool wins = keep && mf_keys[wave][owner] == tb; // this pair's t is the owner's minimum so far
+                    if (wins && tb < before) mf_ranks[wave][owner] = 0u;  // ... a new one: what the slot says belongs to a larger t
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (wins) atomicMax(&mf_ranks[wave][owner], (uint32_t)idx + 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            };
+            // A lane's entries decoded pair by pair (every lane takes every trip): f(live, owner, sphere)
+            auto for_each_pair = [&](uint32_t cnt, auto &&f) {
                 uint32_t k = 0, bits = 0, blk = 0, tile = 0; // (blk: the block's first sphere)
-                for (;;) { // (every lane takes every trip: the fp64 fold below is a sequence of steps the lanes take together)
+                for (;;) {
                     if (bits == 0u && k < cnt) {
                         const uint32_t e = marks[k * 64u + (uint32_t)lane];
                         bits = ~e & 0xFFFFu, blk = (e >> 17) << 5, tile = (e >> 16) & 1u, k += 1;
@@ -762,45 +804,40 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     const bool live = bits != 0u;
                     const uint32_t q = live ? 15u - (uint32_t)__builtin_ctz(bits) : 0u;
                     bits &= bits - 1u;
-                    const uint32_t owner = 32u * tile + ((uint32_t)lane & 31u);
-                    const int idx = (int)(blk + 8u * (q >> 2) + 4u * ((uint32_t)lane >> 5) + (q & 3u));
-                    n_candidates += live ? 1u : 0u;
-                    const FV4 r0 = rays[2u * owner], r1 = rays[2u * owner + 1u];
-                    const SphereHot<F> g = P.sph_hot[live ? idx : 0];
-                    const F ra = r0.w;
-                    const F ocx = r0.x - g.cx, ocy = r0.y - g.cy, ocz = r0.z - g.cz;
-                    const F half_b = ocx * r1.x + ocy * r1.y + ocz * r1.z;
-                    const F c = (ocx * ocx + ocy * ocy + ocz * ocz) - g.r2;
-                    const F disc = half_b * half_b - ra * c;
-                    bool keep = live && !(disc < 0);
-#if RRTX_SKIP_BEHIND
-                    keep = keep && !(half_b > 0 && c > 0); // (sphere_unordered has the argument)
-#endif
-                    F t_hit = 0;
-                    if (keep) { // sphere.h:41-49 without the dependence on the scan order (resolve_pending)
-                        const F sq = fsqrt(disc);
-                        t_hit = (-half_b - sq) / ra;
-                        if (t_hit < t_min) {
-                            t_hit = (-half_b + sq) / ra;
-                            keep = !(t_hit < t_min);
-                        }
-                    }
-                    if (sizeof(F) == 4) {
-                        if (keep) atomicMin(&mf_keys[wave][owner], ((unsigned long long)__float_as_uint((float)t_hit) << 32) | (unsigned long long)(~(uint32_t)idx)); // ds_min_u64: smallest t, then largest index
-                    }
-                    else {
-                        const unsigned long long tb = (unsigned long long)__double_as_longlong((double)t_hit);
-                        const unsigned long long before = mf_keys[wave][owner];
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (keep) atomicMin(&mf_keys[wave][owner], tb);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        const bool wins = keep && mf_keys[wave][owner] == tb; // this pair's t is the owner's minimum so far
-                        if (wins && tb < before) mf_ranks[wave][owner] = 0u;  // ... a new one: what the slot says belongs to a larger t
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (wins) atomicMax(&mf_ranks[wave][owner], (uint32_t)idx + 1u);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    f(live, 32u * tile + ((uint32_t)lane & 31u), (int)(blk + 8u * (q >> 2) + 4u * ((uint32_t)lane >> 5) + (q & 3u)));
+                }
+            };
+            auto drain_mf = [&]() {
+                RRTX_SEC(4);
+                const uint32_t cnt = (uint32_t)(wp - wp0) >> 6;
+#if RRTX_MF_BALANCE
+                // The pairs are few (1.8 a ray) and unevenly held (the busiest lane of 64: 6): they are laid end to end in a queue (a prefix
+                // sum over the lanes' counts) and tested 64 at a time, whoever listed them.
+                uint32_t np = 0;
+                for (uint32_t k = 0; __ballot(k < cnt) != 0ull; ++k) np += k < cnt ? (uint32_t)__builtin_popcount(~marks[k * 64u + (uint32_t)lane] & 0xFFFFu) : 0u;
+                n_candidates += np;
+                const uint32_t incl = wave_scan_add(np), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total <= (uint32_t)kMfQueue) {
+                    uint32_t pos = incl - np;
+                    for_each_pair(cnt, [&](bool live, uint32_t owner, int idx) {
+                        if (live) mf_queue[wave][pos] = (uint16_t)((owner << 10) | (uint32_t)idx);
+                        pos += live ? 1u : 0u;
+                    });
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (uint32_t base = 0; base < total; base += 64u) {
+                        const bool live = base + (uint32_t)lane < total;
+                        const uint32_t e = live ? (uint32_t)mf_queue[wave][base + (uint32_t)lane] : 0u;
+                        test_pair(live, e >> 10, (int)(e & 1023u));
                     }
                 }
+                else
+                    for_each_pair(cnt, test_pair);
+#else
+                for_each_pair(cnt, [&](bool live, uint32_t owner, int idx) {
+                    n_candidates += live ? 1u : 0u;
+                    test_pair(live, owner, idx);
+                });
+#endif
                 wp = wp0;
                 RRTX_SEC(3);
             };
