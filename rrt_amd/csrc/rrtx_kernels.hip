@@ -698,14 +698,15 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             const F a = vlen2<F>(path.d); // sphere.h:36
             best.t = Limits<F>::inf(), best.idx = -1;
             const FilterRay fr = make_filter_ray_mf(path, a);
-            // (not sane - beyond what consider()'s order-free rule is proven for, accel_closest_hit has the same test: the lane scans by itself below, in the reference's order)
-            const bool sane = scans && fr.g < Limits<float>::inf() && a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && vlen2<F>(path.o) <= Limits<F>::coop_big();
-            // the ray's 10 numbers, scaled by a power of two that brings the largest of them under 2^14 (f16 holds 65504)
+            // (not sane - beyond what consider()'s order-free rule is proven for, accel_closest_hit has the same test, or so far out that the
+            // scale below would leave the f16 range, |o|^2 >= 2^38: the lane scans by itself below, in the reference's order)
+            const float fr_max = fmaxf(fmaxf(ffabs(fr.g), ffabs(fr.bx)), fmaxf(ffabs(fr.by), ffabs(fr.bz)));
+            const bool sane = scans && fr.g < Limits<float>::inf() && fr_max < 0x1p38f && a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && vlen2<F>(path.o) <= Limits<F>::coop_big();
+            // the ray's 10 numbers, scaled by a power of two that brings the largest of them under 2^14 (f16 holds 65504; the scale itself, 2^-24 at the least, is one of the operands)
             float lam = 1.0f;
             {
-                const float m = fmaxf(fmaxf(ffabs(fr.g), ffabs(fr.bx)), fmaxf(ffabs(fr.by), ffabs(fr.bz)));
                 int e = 0;
-                (void)__builtin_frexpf(sane ? m : 1.0f, &e);
+                (void)__builtin_frexpf(sane ? fr_max : 1.0f, &e);
                 lam = __builtin_ldexpf(1.0f, e > 14 ? 14 - e : 0);
             }
             const float rv[10] = {fr.nx * fr.nx * lam, fr.ny * fr.ny * lam, fr.nz * fr.nz * lam, fr.nx * fr.ny * lam, fr.nx * fr.nz * lam, fr.ny * fr.nz * lam,
@@ -713,11 +714,15 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             _Float16 hh[10], hl[10];
 #pragma unroll
             for (int q = 0; q < 10; ++q) {
-                const float x = sane ? rv[q] : (q == 9 ? -60000.0f : 0.0f); // (a lane without a ray for this scan, or with one out of range: f = -60000 for every sphere, never a candidate)
+                const float x = sane ? rv[q] : 0.0f;
                 hh[q] = (_Float16)x;
                 hl[q] = (_Float16)(x - (float)hh[q]);
             }
-            const _Float16 ml = (_Float16)(sane ? -lam : 0.0f), z16 = (_Float16)0.0f;
+            // A lane without a ray for this scan, or with one out of range, hands in the column nothing is a candidate for: g = -60000 twice
+            // and thr x -1, so that f = -120000 - thr <= -60000 for a sphere of the table (|thr| <= 60000) and f = -60000 for a padding
+            // record or a sphere listed apart (their only term is thr = 60000)
+            if (!sane) hh[9] = hl[9] = (_Float16)(-60000.0f);
+            const _Float16 ml = (_Float16)(sane ? -lam : -1.0f), z16 = (_Float16)0.0f;
             const H8 ch0 = {hh[0], hl[0], hh[0], hh[1], hl[1], hh[1], hh[2], hl[2]};
             const H8 ch1 = {hh[2], hh[3], hl[3], hh[3], hh[4], hl[4], hh[4], hh[5]};
             const H8 ch2 = {hl[5], hh[5], hh[6], hl[6], hh[6], hh[7], hl[7], hh[7]};

@@ -228,3 +228,27 @@ def test_host_packing_matches_the_model(tmp_path):
             want = want.view(np.uint16)
         assert np.array_equal(got, want), (i, got, want)
     assert out[1 + n_pad].strip() == "roundtrip_bad 0"
+
+
+def test_the_column_of_a_lane_without_a_ray_is_a_candidate_for_nothing():
+    """render_kernel: a lane that does not scan hands in g = -60000 twice and thr x -1.  Against every kind of row - a sphere of the
+    table (|thr| <= 60000), one listed apart, a padding record (both: thr = 60000 alone) - the sum is negative, in any order."""
+    rng = np.random.default_rng(1)
+    n = 20000
+    c = (rng.standard_normal((n, 3)) * np.exp(rng.uniform(-3, 5.5, (n, 1)))).astype(f32)
+    r = np.exp(rng.uniform(np.log(0.01), np.log(300), n)).astype(f32)
+    c[:4] = [(0, 0, 0), (244, 0, 0), (0, -1000, 0), (100, 100, 100)]
+    r[:4] = [244.9, 0.04, 1000, 0.5]
+    S, ok = sphere_terms(c, (r * r).astype(f32), K_MF)
+    assert ok.sum() > 1000 and (~ok).sum() > 1000
+    col = np.zeros(32, f16)
+    col[27] = col[28] = f16(-60000.0)
+    col[29] = col[30] = f16(-1.0)
+    P = S.astype(np.float64) * col.astype(np.float64)[None, :]
+    for order in (np.arange(32), np.arange(31, -1, -1), rng.permutation(32)):
+        acc = np.zeros(n, f32)
+        for j in order:
+            acc = (acc.astype(np.float64) + P[:, j]).astype(f32)
+        assert np.all(acc <= -59000.0)
+    # ... and a padding record / a sphere listed apart against any real ray: thr = 60000 times a negative power of two
+    assert np.all(S[~ok][:, :29] == 0) and np.all(S[~ok][:, 29] == f16(60000.0)) and np.all(S[~ok][:, 30:] == 0)

@@ -17,11 +17,11 @@ pytestmark = pytest.mark.gpu
 CASES = int(os.environ.get("RRTX_MF_CASES", "10"))
 
 
-def render_both(gpu, f, w, h, spp, depth, fp64, **kw):
+def render_both(gpu, f, w, h, spp, depth, fp64, more_flags=0, **kw):
     sc = gpu.Scene(f, w, h, fp64=fp64)
     out = {}
     for flags in (0, gpu.FLAG_SCAN_NO_MFMA):
-        r = gpu.Rrt(w, h, spp, depth, use_bvh=False, fp64=fp64, flags=flags, **kw)
+        r = gpu.Rrt(w, h, spp, depth, use_bvh=False, fp64=fp64, flags=flags | more_flags, **kw)
         fb = r.render(sc)
         out[flags] = (fb, dict(r.stats))
         r.close()
@@ -38,8 +38,13 @@ def test_final_scene_matches_the_oracle_on_the_matrix_cores(gpu, fp64):
     assert mf[1]["block_threads"] == (768 if fp64 else 512)
     assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want)
     assert mf[1]["segments"] == so["segments"] == vu[1]["segments"]
-    # the filter lets through what the exact test then rejects: a few percent more than the 7-FMA filter does
-    assert vu[1]["candidates"] <= mf[1]["candidates"] <= 1.5 * vu[1]["candidates"]
+    # the filter lets through what the exact test then rejects: somewhat more than the 7-FMA filter does (twice its margin; the ground
+    # sphere, listed apart, counts for every segment).  Counted with the whole launch in the render kernel (no hand-off at its end:
+    # what the resume pass tests through the grid is counted differently and varies with the timing of the launch)
+    from rrt_amd._lib import FLAG_NO_TAIL_KERNEL
+    mf, vu = render_both(gpu, f, w, h, spp, 50, fp64, more_flags=FLAG_NO_TAIL_KERNEL)
+    assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want)
+    assert 0.9 * vu[1]["candidates"] <= mf[1]["candidates"] <= 1.25 * vu[1]["candidates"]  # (which camera rays meet a LIST pass depends on the company in their wave)
 
 
 @pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
