@@ -19,7 +19,9 @@
 //   * counter-based RNG keyed by (seed, global pixel index, sample) — no state in memory, no
 //     render_init, identical image for any sharding of the frame.
 //
-// No MFMA: there is no dense contraction on this path (BASELINE.json north_star).
+// Matrix cores: ONE part of the path has a matrix form - the conservative filter of the list scan, a dot product of 31 f16 terms
+// per (ray, sphere) - and runs as two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays for scenes of spheres alone
+// (LDSMODE = 3).  Everything else is per-lane IEEE / integer work on the vector unit.
 #include <hip/hip_runtime.h>
 
 #include "rrtx_device.h"
