@@ -139,3 +139,33 @@ def test_cameras_far_out_scale_the_operands(gpu, tmp_path):
         mf, vu = render_both(gpu, f, w, h, spp, 50, False)
         assert mf[1]["scan_mfma"] == 1
         assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want) and mf[1]["segments"] == so["segments"]
+
+
+def test_every_ray_a_candidate_for_hundreds_of_spheres(gpu, tmp_path):
+    """Nested shells around the camera and the scene: every segment's filter lets 200 spheres through - the lanes' mark lists fill
+    and are emptied in mid-scan, the wave's pairs (12 800) exceed the queue that shares them out and every lane tests its own."""
+    rng = np.random.default_rng(6)
+    shells = [(0.1 * float(rng.standard_normal()), 1.0, 0.1 * float(rng.standard_normal()), 30.0 + 0.35 * i, "amg"[i % 3] if i > 190 else "g") for i in range(200)]
+    spheres = grid_of_spheres(60, rng) + shells
+    f = write_spheres(str(tmp_path / "shells.txt"), spheres, camera="camera 6 2 4 0 0.3 0 0 1 0 40 0.0 7")
+    for fp64 in (False, True):
+        w, h, spp = 48, 32, 3
+        want, so = Oracle(f, w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+        mf, vu = render_both(gpu, f, w, h, spp, 50, fp64)
+        assert mf[1]["scan_mfma"] == 1
+        assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want) and mf[1]["segments"] == so["segments"]
+
+
+def test_rays_beyond_the_operands_scale_scan_sequentially(gpu, tmp_path):
+    """|o|^2 >= 2^38: the power of two that would bring the ray's operands into f16 is itself below f16's range - those lanes take
+    the reference's sequential scan (camera rays; what they scatter into is near the scene again and goes through the matrix cores)."""
+    rng = np.random.default_rng(12)
+    spheres = [(0.0, -1000.0, 0.0, 1000.0, "a")] + grid_of_spheres(120, rng, r=0.4)
+    for dist in (6.0e5, 3.0e6):
+        f = write_spheres(str(tmp_path / "veryfar.txt"), spheres, camera="camera %r %r %r 0 0 0 0 1 0 %r 0.0 %r" % (dist * 0.8, dist * 0.5, dist * 0.33, 1500.0 / dist, dist))
+        w, h, spp = 48, 32, 4
+        for list_passes in (0, -1):  # (-1: no camera-ray lists - the camera rays themselves go through the scan)
+            want, so = Oracle(f, w, h, False).render(spp, 50, 1984, order=1, chunk=8)
+            mf, vu = render_both(gpu, f, w, h, spp, 50, False, list_passes=list_passes)
+            assert mf[1]["scan_mfma"] == 1
+            assert np.array_equal(mf[0], want) and np.array_equal(vu[0], want) and mf[1]["segments"] == so["segments"]
