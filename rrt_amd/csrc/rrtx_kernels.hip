@@ -814,12 +814,22 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     f(live, 32u * tile + ((uint32_t)lane & 31u), (int)(blk + 8u * (q >> 2) + 4u * ((uint32_t)lane >> 5) + (q & 3u)));
                 }
             };
+            // (in mid-scan, when a lane's list is full - practically never: every lane tests what it listed, the scan's registers stay where they are)
+            auto drain_in_scan = [&]() {
+                RRTX_SEC(4);
+                for_each_pair((uint32_t)(wp - wp0) >> 6, [&](bool live, uint32_t owner, int idx) {
+                    n_candidates += live ? 1u : 0u;
+                    test_pair(live, owner, idx);
+                });
+                wp = wp0;
+                RRTX_SEC(3);
+            };
             auto drain_mf = [&]() {
                 RRTX_SEC(4);
                 const uint32_t cnt = (uint32_t)(wp - wp0) >> 6;
 #if RRTX_MF_BALANCE
                 // The pairs are few (1.8 a ray) and unevenly held (the busiest lane of 64: 6): they are laid end to end in a queue (a prefix
-                // sum over the lanes' counts) and tested 64 at a time, whoever listed them.
+                // sum over the lanes' counts) and tested 128 at a time, two to a lane, whoever listed them - the two tests' loads and roots in flight together.
                 uint32_t np = 0;
                 for (uint32_t k = 0; __ballot(k < cnt) != 0ull; ++k) np += k < cnt ? (uint32_t)__builtin_popcount(~marks[k * 64u + (uint32_t)lane] & 0xFFFFu) : 0u;
                 n_candidates += np;
@@ -831,10 +841,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                         pos += live ? 1u : 0u;
                     });
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    for (uint32_t base = 0; base < total; base += 64u) {
-                        const bool live = base + (uint32_t)lane < total;
-                        const uint32_t e = live ? (uint32_t)mf_queue[wave][base + (uint32_t)lane] : 0u;
-                        test_pair(live, e >> 10, (int)(e & 1023u));
+                    for (uint32_t base = 0; base < total; base += 128u) {
+                        const bool live0 = base + (uint32_t)lane < total, live1 = base + 64u + (uint32_t)lane < total;
+                        const uint32_t e0 = live0 ? (uint32_t)mf_queue[wave][base + (uint32_t)lane] : 0u, e1 = live1 ? (uint32_t)mf_queue[wave][(base + 64u + (uint32_t)lane) & (uint32_t)(kMfQueue - 1)] : 0u;
+                        test_pair(live0, e0 >> 10, (int)(e0 & 1023u));
+                        if (__ballot(live1) != 0ull) test_pair(live1, e1 >> 10, (int)(e1 & 1023u));
                     }
                 }
                 else
@@ -889,7 +900,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             for (int b = 0; b < n_blocks; ++b) {
                 f1 = products(a0, a1, 1);
                 a0 = table_block(b + 1, 0), a1 = table_block(b + 1, 1);
-                if (__ballot(wp > wp_full) != 0ull) drain_mf();
+                if (__ballot(wp > wp_full) != 0ull) drain_in_scan();
                 look(f0, b, 0);
                 f0 = products(a0, a1, 0);
                 look(f1, b, 1);
