@@ -281,7 +281,7 @@ struct Worker {
 
         double seconds = 0, samples = 0, bytes_algorithmic = 0;
         unsigned long long segments = 0, prim_tests = 0;
-        int blocks = 0, accel_cells = 0, accel_exact = 1;
+        int blocks = 0, accel_cells = 0, accel_exact = 1, scan_mfma = 0;
         std::string how;
         if (group_size > 1) {
             err << "HIP Devices:";
@@ -304,7 +304,7 @@ struct Worker {
             rc = rrtx_render(ctx, fb->data(), &st);
             if (rc) die(rc, err.str());
             seconds = st.kernel_ms / 1000.0, samples = (double)st.samples, bytes_algorithmic = (double)st.bytes_algorithmic;
-            segments = st.segments, prim_tests = st.prim_tests, blocks = st.grid_blocks, accel_cells = st.accel_cells, accel_exact = st.accel_exact;
+            segments = st.segments, prim_tests = st.prim_tests, blocks = st.grid_blocks, accel_cells = st.accel_cells, accel_exact = st.accel_exact, scan_mfma = st.scan_mfma;
         }
         err << "took " << seconds << " seconds.\n";
         char hostname[HOST_NAME_MAX + 1];
@@ -317,7 +317,7 @@ struct Worker {
             << blocks << "," << prm.threads_x << "," << prm.threads_y << "," << seconds << "\n";
         if (seconds > 0)
             err << "rate," << samples / seconds / 1e6 << " Msamples/s," << how << segments << " segments," << prim_tests << " primitive tests," << bytes_algorithmic / seconds / 1e9
-                << " GB/s algorithmic," << (accel_cells ? "grid of " + std::to_string(accel_cells) + " cells" : std::string("list scan"))
+                << " GB/s algorithmic," << (accel_cells ? "grid of " + std::to_string(accel_cells) + " cells" : std::string(scan_mfma ? "list scan (filter on the matrix cores)" : "list scan"))
                 << (accel_exact ? "" : ",approximate rule (fp32 triangles gridded under an empirical inflation: -X or -b for the list scan's bits)") << "\n";
         rrtx_scene_free(scene);
         log(err.str());
