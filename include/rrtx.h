@@ -166,7 +166,7 @@ typedef struct rrtx_params {
  * only used for this where it is proven to reproduce the scan bit for bit). */
 #define RRTX_FLAG_NO_TAIL_GRID 128
 /* List scan of a scene of spheres alone: keep the conservative filter on the vector unit (7 FMAs per ray and sphere)
- * instead of the matrix cores (one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays; A/B switch, identical images). */
+ * instead of the matrix cores (two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays; A/B switch, identical images). */
 #define RRTX_FLAG_SCAN_NO_MFMA 256
 
 typedef struct rrtx_stats {

@@ -173,7 +173,7 @@ template <typename F> int upload_scene(rrtx_ctx *c, const rrtx_scene_desc *s)
     c->lds_mode = 0;
     if (c->use_filter && hfil.size() * sizeof(SphereHot<float>) <= (size_t)kLdsSceneBytes && !(c->p.flags & RRTX_FLAG_SCAN_SCALAR_ONLY))
         c->lds_mode = (c->p.flags & RRTX_FLAG_SCAN_LDS_ONLY) ? 2 : 1; // (fp64 too: its filter is the fp32 one)
-    // scenes of spheres alone whose f16 operands fit LDS three blocks to a CU: the filter as one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays
+    // scenes of spheres alone whose f16 operands fit LDS (one copy per block): the filter as two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays
     if (c->lds_mode == 1 && packed.tail_ok && s->num_spheres > 0 && s->num_moving_spheres == 0 && s->num_triangles == 0 && (size_t)mf_padded(n_pad) * 64 <= (size_t)kLdsMfBytes && !(c->p.flags & (RRTX_FLAG_SCAN_NO_MFMA | RRTX_FLAG_VERIFY_LISTS))) {
         MfTable mf;
         pack_mf_table<F>(hhot, s->num_spheres, n_pad, mf);

@@ -683,12 +683,12 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // ---------------- LDSMODE == 3: the scan of this iteration, by the whole wave --------------------------------------------
         // The filter on the matrix cores (scenes of spheres alone; rrtx_pack.h: pack_mf_table has the operands and the bound):
         //   f = (c.n)^2 + b.c + g - thr  as ONE dot product of 31 f16 terms,
-        // so one v_mfma_f32_16x16x32_f16 per 16 spheres x 16 rays leaves the filter's VALUE in the result registers and the vector
-        // unit a compare per pair (the 7 FMAs of filter_value() are gone).  The instruction wants every lane of the wave - a lane
-        // holds one sphere's terms, one ray's terms and the results of 4 spheres x 4 OTHER lanes' rays - so the scan runs HERE,
-        // before the lanes part ways: a lane that does not scan in this iteration (not alive, no pass for it) hands in a ray
-        // nothing is a candidate for.  The lane that HOLDS a result lists the pair (ray, sphere) and later puts it to the exact
-        // test with the ray's record from LDS; hits go to the ray's owner through an LDS minimum over (t, index) - consider()'s
+        // so two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays leave the filter's VALUE in the result registers and the vector
+        // unit the look at a sign per pair (the 7 FMAs of filter_value() are gone).  The instruction wants every lane of the wave - a
+        // lane holds one sphere's terms, one ray's terms and the results of 16 spheres for ANOTHER lane's ray - so the scan runs HERE,
+        // before the lanes part ways: a lane that does not scan in this iteration (not alive, no pass for it) hands in a column
+        // nothing is a candidate for.  The lane that HOLDS a result marks the pair (ray, sphere); the marked pairs are then put to the
+        // exact test with the ray's record from LDS, and hits go to the ray's owner through an LDS minimum over (t, index) - consider()'s
         // order-free rule, as in dense_candidates().  `best` is then what the scan section further down would have found.
         if constexpr (LDSMODE == 3) {
         const bool scans = alive && P.max_depth > 0 && !list_pass;

@@ -1,5 +1,8 @@
+"""Developer script (GPU box): segments, scanned segments and candidates (pairs that reached the exact test) of the list scan on final.txt
+per filter (flag 256: vector unit) and end-of-launch mode (128: tail kernel, 8: no hand-off) - how the idle lanes' column was found wanting."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rrt_amd
 from _oracle import scene_path
 for (w,h,spp) in ((120,80,8),(600,400,16)):
