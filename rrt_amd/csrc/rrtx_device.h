@@ -21,7 +21,7 @@ namespace rrtx {
 constexpr int kSphereUnroll = 8;  // tests per straight-line block (fp32; fp64 uses half)
 constexpr int kSpherePad = 16;    // the sphere tables are padded to a multiple of this (two blocks)
 constexpr int kLdsSceneBytes = 48 * 1024; // largest scan table mirrored in LDS
-constexpr int kLdsMfBytes = 36 * 1024;    // ... and largest table of f16 operands for the filter on the matrix cores (64 bytes per sphere: three blocks to a CU)
+constexpr int kLdsMfBytes = 36 * 1024;    // ... and largest table of f16 operands for the filter on the matrix cores (64 bytes per sphere, whole blocks of 32: one copy per block of 512 / 768 threads, two such blocks / one to a CU)
 #ifndef RRTX_CAND_CAP
 #define RRTX_CAND_CAP 16
 #endif
