@@ -48,7 +48,7 @@ template <typename F> void pack_unit(const F v[3], F out[3])
 // x = x_h + x_l (22 bits), and the three leading cross products x_h y_h + x_h y_l + x_l y_h are kept: 6 x 3 + 3 x 3 terms, two for
 // g (x 1), two for thr (x -1): 31 of the instruction's 32.  What is dropped (x_l y_l: 2^-22 of a term) and how the products are
 // added up (f32) is far inside the margins the filter has anyway (K eps (|o|^2 + |c|^2 + r^2), K = kFilterKMf: the numerical search of
-// tests/test_filter_bound.py finds no false negative from K = 16 up).  Spheres the f16 operands cannot hold (a monomial or the
+// tests/test_filter_mfma.py finds no false negative from K = 16 up).  Spheres the f16 operands cannot hold (a monomial or the
 // threshold beyond 60000: the r = 1000 ground sphere) or resolve (r^2 < 1e-3) are listed apart (`big`) and tested exactly.
 //
 // Table: 32 halves per sphere, [block of 32 spheres][half of the terms (16)][lane][8]: lane l of a wave reads 16 bytes at
