@@ -554,7 +554,10 @@ def main():
 
         # ---- the binding unit: the vector issue port, which the matrix instructions of the scan's filter share with everything else
         clock = CLOCK_HZ
-        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD (a matrix instruction = %d)" % MFMA_ISSUE, "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL + ", ...>", "kernel_ms": round(kernel_ms, 3)}
+        roof = {"bound": "valu_issue", "unit": "VALU wave-instructions/clk/SIMD (a matrix instruction = %d)" % MFMA_ISSUE, "peak": VALU_PEAK, "kernel": "rrtx::" + LIST_KERNEL + ", ...>", "kernel_ms": round(kernel_ms, 3),
+                "note": "the SIMD's one vector issue port is what the kernel's two kinds of work share: the scan filter (two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays, the results' signs "
+                        "shifted into a mask: 1.2 vector instructions per sphere and wave where rounds 1 - 2 spent 8) and the per-lane rest of a path tracer (camera rays, exact tests, shading); rounds 1 - 2 "
+                        "reported 0.78 of this peak at 6 200 Msamples/s - fewer instructions, not a busier port, is where the time went; `mfma` prices the matrix instructions alone"}
         # what the run can count itself: the filter's matrix instructions - per scanned wave-segment (>= scanned segments / 64) and block of 32
         # spheres, 2 tiles of 32 rays x 2 halves of the 32 terms
         n_blocks = (488 + MF_BLOCK - 1) // MF_BLOCK
