@@ -25,7 +25,13 @@
 extern "C" {
 #endif
 
-#define RRTX_VERSION_STRING "rrtx 0.1 (gfx950)"
+#define RRTX_VERSION_STRING "rrtx 0.4 (gfx950)"
+/* Layout version of the structs below.  rrtx_stats and rrtx_group_stats are filled with sizeof(the library's struct) bytes:
+ * a host compiled against a header of another RRTX_ABI_VERSION must not pass its own structs.  Check once at start-up:
+ *     if (rrtx_abi_version() != RRTX_ABI_VERSION) refuse;
+ * History: 3 = round 3 (rrtx_stats grew walk_cells / walk_pairs, rrtx_group_stats the RCCL fields, without a bump: that
+ * was a silent break); 4 = rrtx_stats.convergence_faults. */
+#define RRTX_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define RRTX_OK 0
@@ -196,6 +202,8 @@ typedef struct rrtx_stats {
     uint64_t walk_cells;     /* grid cells the walks stepped through, and ...                                              */
     uint64_t walk_pairs;     /* ... (ray, entry) pairs they tested - counted by the densely pairing variants (scenes with
                                 triangles / moving spheres under use_bvh) only, 0 elsewhere                                */
+    uint64_t convergence_faults; /* waves that reached a wave-wide step (matrix-core scan, dense pairing) with lanes masked off: must
+                                be 0 - the kernels count it instead of assuming it (always collected)                      */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */
@@ -214,6 +222,7 @@ typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */
 typedef struct rrtx_ctx rrtx_ctx;
 
 const char *rrtx_version(void);
+int rrtx_abi_version(void); /* the RRTX_ABI_VERSION the library was built with */
 /* Thread-local description of the last failure on the calling thread ("" if none). */
 const char *rrtx_last_error(void);
 
@@ -282,11 +291,10 @@ typedef struct rrtx_group rrtx_group;
  * blocks then move with device-to-device copies instead.  Rejected without this flag. */
 #define RRTX_GROUP_REHEARSAL 1
 /* RCCL greets on STDOUT when a communicator is built ("RCCL version : ..."), and stdout is where `rrt` prints its PPM
- * (main.cpp:142).  rrtx_group_create therefore points file descriptor 1 at stderr while ncclCommInitAll runs (dup2 /
- * restore).  That is PROCESS-WIDE and not synchronised with other threads: bytes another thread writes to stdout in
- * that window land on stderr.  A caller that owns stdout and writes to it from other threads passes this flag and
- * does the diversion itself, or creates its groups before those threads exist (`rrt` does: a group is created by the
- * first job of its worker, before any writer task). */
+ * (main.cpp:142).  Up to ABI 3 rrtx_group_create pointed file descriptor 1 at stderr while ncclCommInitAll ran unless this
+ * flag was passed; a library should not touch a process-wide descriptor, so since ABI 4 it never does: a host that owns
+ * stdout diverts it itself around rrtx_group_create (rrt_main.cpp does, before any writer task exists; so does
+ * rrt_amd.RrtGroup).  The flag is still accepted, and ignored. */
 #define RRTX_GROUP_KEEP_STDOUT 2
 
 typedef struct rrtx_group_stats {

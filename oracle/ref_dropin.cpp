@@ -89,6 +89,7 @@ vec3 *Rrt::render(scene *the_scene) // rrt.cu:186 / rrt.cpp:99
     std::cerr << "Rendering a " << image_width << "x" << image_height << " image with " << samples_per_pixel << " samples per pixel through librrtx ("
               << rrtx_version() << ").\n"; // rrt.cu:198-202
     rrtx_ctx *ctx = nullptr;
+    check(rrtx_abi_version() == RRTX_ABI_VERSION ? 0 : RRTX_E_UNSUPPORTED); // the library writes sizeof(ITS rrtx_stats) below
     check(rrtx_create(&p, &ctx));                      // Rrt::Rrt
     check(rrtx_set_scene(ctx, &d));                    // replaces create_world<<<1,1>>>, rrt.cu:266
     fb = new vec3[(size_t)image_width * image_height]; // vec3 = 3 x FP_T: the layout rrtx_render writes

@@ -78,6 +78,7 @@ class Stats(C.Structure):  # rrtx_stats
         ("scan_mfma", C.c_int32),
         ("walk_cells", C.c_uint64),
         ("walk_pairs", C.c_uint64),
+        ("convergence_faults", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -161,6 +162,10 @@ def _sig(name, restype, argtypes):
 
 
 _sig("rrtx_version", C.c_char_p, [])
+_sig("rrtx_abi_version", C.c_int, [])
+ABI_VERSION = 4  # RRTX_ABI_VERSION of include/rrtx.h as mirrored by the Structures above
+if lib.rrtx_abi_version() != ABI_VERSION:
+    raise ImportError("rrt_amd: %s was built with RRTX_ABI_VERSION %d, this binding mirrors %d - rebuild with `make`" % (LIB_PATH, lib.rrtx_abi_version(), ABI_VERSION))
 _sig("rrtx_last_error", C.c_char_p, [])
 _sig("rrtx_device_count", C.c_int, [])
 _sig("rrtx_query", C.c_int, [C.c_int, C.POINTER(DevInfo)])

@@ -247,7 +247,18 @@ struct Worker {
 
         if (group_size > 1) {
             if (!group) {
+                // RCCL greets on stdout while the communicators are built, and stdout is where the PPM goes (main.cpp:142): file descriptor 1
+                // points at stderr for the duration.  This is the host's business, not the library's, and it is safe HERE: a group is created
+                // by the first job of this worker, before any writer task exists.
+                fflush(stdout);
+                const int saved_stdout = ::dup(1);
+                if (saved_stdout >= 0) (void)::dup2(2, 1);
                 rc = rrtx_group_create(&prm, group_size, group_devices.data(), group_rehearsal ? RRTX_GROUP_REHEARSAL : 0, &group);
+                fflush(stdout);
+                if (saved_stdout >= 0) {
+                    (void)::dup2(saved_stdout, 1);
+                    ::close(saved_stdout);
+                }
                 if (rc) die(rc, err.str());
             }
             rc = rrtx_group_set_scene(group, &desc);
@@ -354,6 +365,10 @@ struct Worker {
 int main(int argc, char *argv[])
 {
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); // (the hosts of this pool only support dmabuf IPC; RCCL wants it set before the runtime starts)
+    if (rrtx_abi_version() != RRTX_ABI_VERSION) { // the library fills this binary's rrtx_stats / rrtx_group_stats with ITS sizeof
+        std::cerr << "librrtx.so has struct layout version " << rrtx_abi_version() << ", this binary was built for " << RRTX_ABI_VERSION << "\n";
+        return 99;
+    }
     rrtx_params prm;
     std::memset(&prm, 0, sizeof prm);
     prm.image_width = 1200;

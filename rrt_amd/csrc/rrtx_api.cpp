@@ -111,16 +111,12 @@ namespace {
 
 int rows_of_shard(const rrtx_params &p, std::vector<int32_t> *out)
 {
-    int count = 0;
-    const int n = p.shard_count < 1 ? 1 : p.shard_count;
-    const int T = p.tile_rows < 1 ? 1 : p.tile_rows;
-    for (int j = 0; j < p.image_height; ++j) {
-        if ((j / T) % n == p.shard_rank) {
-            if (out) out->push_back(j);
-            ++count;
-        }
-    }
-    return count;
+    // (the plan's one statement: rrtx_device.h, held against its definition - row j belongs to shard (j / T) mod N - by tests/gather_plan_check.cpp)
+    const uint32_t n = p.shard_count < 1 ? 1u : (uint32_t)p.shard_count, T = p.tile_rows < 1 ? 1u : (uint32_t)p.tile_rows;
+    const uint32_t count = shard_row_count((uint32_t)p.image_height, T, n, (uint32_t)p.shard_rank);
+    if (out)
+        for (uint32_t lr = 0; lr < count; ++lr) out->push_back((int32_t)shard_local_to_frame_row(lr, T, n, (uint32_t)p.shard_rank));
+    return (int)count;
 }
 
 // The per-scene device buffers (tables, grid, camera-ray lists, parked-item buffers: 200 MB at 1280x720) survive from scene
@@ -319,6 +315,7 @@ int drain_events(rrtx_ctx *c, double *last_ms)
 extern "C" {
 
 const char *rrtx_version(void) { return RRTX_VERSION_STRING; }
+int rrtx_abi_version(void) { return RRTX_ABI_VERSION; }
 const char *rrtx_last_error(void) { return g_error.c_str(); }
 
 int rrtx_device_count(void)
@@ -479,9 +476,14 @@ void rrtx_destroy(rrtx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_grid_cell_start, c->d_grid_cell_prims, c->d_grid_always, c->d_plist, c->d_tail_units, c->d_tail_rad, c->d_tail_items, c->d_hot, c->d_filter, c->d_cold, c->d_msph, c->d_tri, c->d_tri_scan, c->d_mat, c->d_queue, c->d_partial, c->d_rows};
+    for (int i = 0; i < c->ev_pending; ++i) (void)hipEventSynchronize(c->ev_stop[i]); // (renders enqueued on a caller's stream)
+    free_scene_buffers(c); // everything rrtx_set_scene allocated: tables (the matrix form's operands too), grid, lists, parked-item buffers
+    void *bufs[] = {c->d_queue, c->d_partial, c->d_rows};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+#ifdef RRTX_DIAG
+    if (c->d_diag) (void)hipFree(c->d_diag);
+#endif
     for (int i = 0; i < kEventRing; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -604,35 +606,32 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
 #if defined(RRTX_SECTION_DIAG) || defined(RRTX_RESUME_DIAG)
     RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 512, st));
 #else
-    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, (c->p.collect_stats || (c->p.flags & RRTX_FLAG_VERIFY_LISTS)) ? 256 + 48 : 256, st));
+    RRTX_HIP(hipMemsetAsync(c->d_queue, 0, 256 + 64, st)); // (counters 0 .. 7: statistics, and the convergence faults, which are counted whether statistics are on or not)
 #endif
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->use_partial ? c->d_partial : d_rows;
     const FinalizeShape shape = {(uint32_t)((size_t)c->local_rows * c->p.image_width), c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel};
-    if (c->p.fp64) {
-        KernelParams<double> P = make_params<double>(c, out, c->accel);
-        RRTX_HIP(launch_render<double>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) {
-            if (c->accel || c->tail_grid)
-                RRTX_HIP(launch_resume<double>(make_params<double>(c, out, true), c->use_filter, c->resume_blocks, st));
-            else
-                RRTX_HIP(launch_tail<double>(P, c->use_filter, c->tail_blocks, st));
-        }
-        if (c->use_partial) RRTX_HIP(launch_finalize<double>((const double *)c->d_partial, (double *)d_rows, shape, st));
+    // The launches of one render.  If one of them fails after an earlier one was enqueued, that kernel may still be reading the
+    // scene's tables while the caller, holding an error, goes on to rrtx_set_scene (which waits for stop EVENTS only, and none
+    // will have been recorded): the stream is drained before the error is returned.
+    auto enqueue = [&](auto fp) -> hipError_t {
+        typedef decltype(fp) F;
+        KernelParams<F> P = make_params<F>(c, out, c->accel);
+        hipError_t e = launch_render<F>(P, c->use_filter, c->lds_mode, c->grid_blocks, st);
+        if (e == hipSuccess && c->tail_capacity)
+            e = (c->accel || c->tail_grid) ? launch_resume<F>(make_params<F>(c, out, true), c->use_filter, c->resume_blocks, st) : launch_tail<F>(P, c->use_filter, c->tail_blocks, st);
+        if (e == hipSuccess && c->use_partial) e = launch_finalize<F>((const F *)c->d_partial, (F *)d_rows, shape, st);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_stop[slot], st);
+        return e;
+    };
+    const hipError_t le = c->p.fp64 ? enqueue(double()) : enqueue(float());
+    if (le != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        char buf[256];
+        snprintf(buf, sizeof buf, "rrtx_render_device: HIP error = %u (%s) while enqueueing the render", (unsigned)le, hipGetErrorString(le));
+        return fail(RRTX_E_DEVICE, buf);
     }
-    else {
-        KernelParams<float> P = make_params<float>(c, out, c->accel);
-        RRTX_HIP(launch_render<float>(P, c->use_filter, c->lds_mode, c->grid_blocks, st));
-        if (c->tail_capacity) {
-            if (c->accel || c->tail_grid)
-                RRTX_HIP(launch_resume<float>(make_params<float>(c, out, true), c->use_filter, c->resume_blocks, st));
-            else
-                RRTX_HIP(launch_tail<float>(P, c->use_filter, c->tail_blocks, st));
-        }
-        if (c->use_partial) RRTX_HIP(launch_finalize<float>((const float *)c->d_partial, (float *)d_rows, shape, st));
-    }
-    RRTX_HIP(hipEventRecord(c->ev_stop[slot], st));
     c->ev_pending = slot + 1;
     return RRTX_OK;
 }
@@ -688,6 +687,13 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->renders = (int32_t)(c->renders_total - before_n);
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
+        {
+            unsigned long long faults = 0;
+            RRTX_HIP(hipMemcpy(&faults, c->d_counters + 6, sizeof faults, hipMemcpyDeviceToHost));
+            stats->convergence_faults = faults;
+            // (a frame rendered by a wave that was short of lanes in a wave-wide step is not to be trusted: an error, not a statistic)
+            if (faults) return fail(RRTX_E_DEVICE, "rrtx_collect: " + std::to_string(faults) + " wave(s) reached a wave-wide step (matrix-core scan / dense pairing) with lanes masked off; the frame is invalid");
+        }
         if (c->p.collect_stats) {
             unsigned long long ctr[6] = {0, 0, 0, 0, 0, 0};
             RRTX_HIP(hipMemcpy(ctr, c->d_counters, sizeof ctr, hipMemcpyDeviceToHost));

@@ -212,6 +212,37 @@ struct GatherShape {
     uint32_t row_off[kMaxGroup]; // rows of the shards before shard r in the gathered buffer
 };
 
+// The row-tile plan, in ONE place for the three that must agree: which frame rows a shard renders (rrtx_api.cpp: rows_of_shard,
+// rrtx_shard_rows), where a shard's local row lies in the frame (the render kernel: task_decode), and where a frame row lies in the
+// gathered buffer (deinterleave_kernel).  tests/gather_plan_check.cpp compiles these for the host and holds them against each other
+// and against rrt_amd/dist.py's shard_rows for N = 1 .. 9 members, ragged last tiles and more members than tiles.
+#if defined(__HIPCC__)
+#define RRTX_HD __host__ __device__ __forceinline__
+#else
+#define RRTX_HD inline
+#endif
+// rows of an H-row frame that belong to shard `rank` of N (tiles of T rows, tile t to shard t mod N)
+RRTX_HD uint32_t shard_row_count(uint32_t H, uint32_t T, uint32_t N, uint32_t rank)
+{
+    const uint32_t tiles = (H + T - 1u) / T;            // the last one may be ragged
+    const uint32_t mine = tiles > rank ? (tiles - rank + N - 1u) / N : 0u; // tiles rank, rank + N, ...
+    if (mine == 0u) return 0u;
+    const uint32_t last = rank + (mine - 1u) * N;       // my last tile: ragged if it is the frame's last
+    return mine * T - (last == tiles - 1u ? tiles * T - H : 0u);
+}
+// local row lr of shard `rank` -> frame row (what task_decode computes with its launch-constant divisions)
+RRTX_HD uint32_t shard_local_to_frame_row(uint32_t lr, uint32_t T, uint32_t N, uint32_t rank)
+{
+    const uint32_t tile = lr / T;
+    return (tile * N + rank) * T + (lr - tile * T);
+}
+// frame row j -> row of the gathered buffer (the shards' compact blocks side by side, shard r from row_off[r] on)
+RRTX_HD uint32_t gather_source_row(const GatherShape &S, uint32_t j)
+{
+    const uint32_t tile = j / S.tile_rows, r = tile % S.n_shards;
+    return S.row_off[r] + (tile / S.n_shards) * S.tile_rows + (j - tile * S.tile_rows);
+}
+
 // Samples handed out as single-sample tasks at the end of the queue, per compute unit, when
 // rrtx_params.taper_samples is 0 (automatic).  Measured on final.txt 1200x800 with the queue-over flag,
 // pool parking and the unit split of parked items in place: none is best from spp 48 up (spp 504: 78.6 ms

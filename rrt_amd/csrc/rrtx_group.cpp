@@ -12,7 +12,6 @@
 // `rrt` never pays for it; inside a Python process that imported torch the already-mapped copy is reused, as
 // for the HIP runtime itself (rrt_amd/_lib.py).
 #include <dlfcn.h>
-#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -329,18 +328,10 @@ int rrtx_group_create(const rrtx_params *params, int n_devices, const int32_t *d
         g->rccl = load_rccl(why);
         if (!g->rccl) return bail(set_error(RRTX_E_DEVICE, "rrtx_group_create: " + why));
         g->comms.assign(n_devices, nullptr);
-        // RCCL greets on STDOUT ("RCCL version : ..."), and stdout is where `rrt` prints its PPM (main.cpp:142): while the
-        // communicators are built, file descriptor 1 points at stderr
-        // (process-wide, see RRTX_GROUP_KEEP_STDOUT in rrtx.h: a caller that writes to stdout from other threads diverts it itself)
-        fflush(stdout);
-        const int saved_stdout = (flags & RRTX_GROUP_KEEP_STDOUT) ? -1 : ::dup(1);
-        if (saved_stdout >= 0) (void)::dup2(2, 1);
+        // (RCCL greets on STDOUT, "RCCL version : ...".  Round 3 pointed file descriptor 1 at stderr here while the communicators were
+        // built - a process-wide side effect a library has no business with; since ABI 4 the hosts that own stdout do it themselves:
+        // rrt_main.cpp around its rrtx_group_create, rrt_amd/render.py's RrtGroup.  RRTX_GROUP_KEEP_STDOUT is accepted and ignored.)
         ncclResult_t r = g->rccl->CommInitAll(g->comms.data(), n_devices, g->devs.data());
-        fflush(stdout);
-        if (saved_stdout >= 0) {
-            (void)::dup2(saved_stdout, 1);
-            ::close(saved_stdout);
-        }
         if (r != ncclSuccess) return bail(set_error(RRTX_E_DEVICE, std::string("rrtx_group_create: ncclCommInitAll: ") + g->rccl->GetErrorString(r)));
         int v = 0;
         if (g->rccl->GetVersion(&v) == ncclSuccess) g->rccl_version = v;

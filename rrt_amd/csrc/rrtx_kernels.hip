@@ -235,12 +235,12 @@ template <typename F> __device__ __forceinline__ HitInfo<F> sequential_closest_h
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
     for (int q = 0; q < P.n_sph; ++q) {
         const SphereHot<F> gq = P.sph_hot[q];
-        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
+        refine_sphere<F, true>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
     }
     for (int q = 0; q < P.n_msph; ++q) {
         const MovingSphereRec<F> ms = P.msph[q];
         const V3<F> cen = msphere_center<F>(ms, path.tm);
-        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
+        refine_sphere<F, true>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
     }
     for (int q = 0; q < P.n_tri; ++q) {
         F tt;
@@ -275,8 +275,14 @@ template <typename F, bool SO, int CAP, typename HotTab, typename PrimTab>
 __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const HotTab &hot, const PrimTab &cell_prims, const uint16_t *plist, const Path<F> &path, F a, const WalkRanges &R,
                                                   F t_min, bool is_list, uint32_t n_own, int lane, uint32_t *marks, uint32_t *ranks, unsigned long long *keys)
 {
+    // "All 64 lanes, converged" is enforced, not assumed: the prefix sums (DPP), the read of lane 63 and the bpermutes below take operands from
+    // every lane, and a lane masked off would feed them whatever its registers happen to hold.  A wave that arrives here short of lanes counts
+    // a fault (rrtx_stats.convergence_faults; every GPU test asserts 0), and the trip count is bounded by what 64 lanes can list whatever the sum says.
+    if (__builtin_expect(__builtin_amdgcn_read_exec() != ~0ull, 0)) atomicAdd(&P.counters[6], 1ull);
     const uint32_t incl = wave_scan_add(n_own), off = incl - n_own;
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    constexpr uint32_t kMostPairs = 64u * kDenseCellMax * (uint32_t)kDenseRanges;
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    total = total < kMostPairs ? total : kMostPairs;
     keys[lane] = ~0ull;
     if (sizeof(F) == 8) ranks[lane] = 0u;
     const int msph_base = P.n_sph_padded, tri_base = P.n_sph_padded + P.n_msph;
@@ -451,7 +457,6 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t n_walk_cells = 0, n_walk_pairs = 0; // dense variants: cells stepped through, (ray, entry) pairs tested
-    uint32_t walk_turns = 0;                     // dense variants: slices the current segment's walk has taken (a bound on them ends any walk: see there)
 #ifdef RRTX_RESUME_DIAG
     const unsigned long long resume_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -699,6 +704,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             typedef F FV4 __attribute__((ext_vector_type(4)));
             // the wave's slice of cand_lds: [lists: 8 slots x 64 lanes x 32 bits][ray records: 64 x {o, a, d, -}], and before both the
             // 4 KB through which the rays' operands are transposed
+            if (__builtin_expect(__builtin_amdgcn_read_exec() != ~0ull, 0)) atomicAdd(&P.counters[6], 1ull); // (the matrix instruction, the transposes and the queue below want all 64 lanes: rrtx_stats.convergence_faults)
             unsigned char *const area = (unsigned char *)&cand_lds[wave][0][0];
             U4 *const stage = (U4 *)area;
             uint32_t *const marks = (uint32_t *)area; // slot s of lane l at [s * 64 + l]: block << 16 | the signs of the lane's 16 results for it
@@ -979,25 +985,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     }
                 }
                 if (VERIFY) { // test build of the kernel: the list must reproduce the full sequential scan
-                    HitInfo<F> full;
-                    full.t = Limits<F>::inf();
-                    full.idx = -1;
-                    for (int q = 0; q < n_sph; ++q) {
-                        const SphereHot<F> gq = P.sph_hot[q];
-                        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
-                    }
-                    for (int q = 0; q < n_msph; ++q) {
-                        const MovingSphereRec<F> ms = P.msph[q];
-                        const V3<F> cen = msphere_center<F>(ms, path.tm);
-                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
-                    }
-                    for (int q = 0; q < n_tri; ++q) {
-                        F tt;
-                        if (triangle_test<F, true>(P.tri[q], path, t_min, full.t, tt)) {
-                            full.t = tt;
-                            full.idx = tri_base + q;
-                        }
-                    }
+                    const HitInfo<F> full = sequential_closest_hit<F>(P, path, a, t_min);
                     if (full.idx != best.idx || !(full.t == best.t)) atomicAdd(&P.counters[2], 1ull);
                 }
             }
@@ -1020,25 +1008,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (r == kWalkFarScan) walk_cell = kCoopWait; // (waits, as a walk in progress, for the next top of the loop)
                 still_walking = in_walk = r == kWalkGoesOn || r == kWalkFarScan;
                 if (VERIFY && !need_scan && !still_walking) { // test build of the kernel: the walk must reproduce the full sequential scan
-                    HitInfo<F> full;
-                    full.t = Limits<F>::inf();
-                    full.idx = -1;
-                    for (int q = 0; q < n_sph; ++q) {
-                        const SphereHot<F> gq = P.sph_hot[q];
-                        refine_sphere<F>(gq.cx, gq.cy, gq.cz, gq.r2, path, a, t_min, q, full);
-                    }
-                    for (int q = 0; q < n_msph; ++q) {
-                        const MovingSphereRec<F> ms = P.msph[q];
-                        const V3<F> cen = msphere_center<F>(ms, path.tm);
-                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, full);
-                    }
-                    for (int q = 0; q < n_tri; ++q) {
-                        F tt;
-                        if (triangle_test<F, true>(P.tri[q], path, t_min, full.t, tt)) {
-                            full.t = tt;
-                            full.idx = tri_base + q;
-                        }
-                    }
+                    const HitInfo<F> full = sequential_closest_hit<F>(P, path, a, t_min);
                     if (full.idx != best.idx || !(full.t == best.t)) atomicAdd(&P.counters[2], 1ull);
                 }
             }
@@ -1312,10 +1282,11 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             if (walking) {
                 in_walk = accel_walk_decide<F>(best, t_last, slack_t, ended) == kWalkGoesOn;
                 resolved = !in_walk;
-                // No walk may go on for ever: every slice advances at least one cell, so a walk that has taken more slices than the grid has
-                // cells along its three axes is a bug - and is ended by the reference's own scan of this segment (its answer is the answer).
-                walk_turns = in_walk ? walk_turns + 1u : 0u;
-                if (__builtin_expect(walk_turns > (uint32_t)(C.grid.dims[0] + C.grid.dims[1] + C.grid.dims[2] + 8), 0)) in_walk = false, resolved = false, need_scan = true, walk_turns = 0u;
+                // (Every walk ends: a slice takes up at least its first cell - accel_walk_prepare: a cell of more entries than four ranges hold is
+                // tested on the spot, any other fits the four empty ranges a slice starts with - and the DDA moves one cell along one axis in a
+                // fixed direction per step, NaN or infinite boundary distances included (the comparisons then pick z), so it leaves the grid
+                // after at most dims[0] + dims[1] + dims[2] steps; tests/path_host_check.cpp runs the same source on 2 M hostile rays.  Round 3
+                // carried a counter here that sent a walk of more slices than that to the reference's scan; it never fired - round 4 removed it.)
             }
             if (VERIFY && resolved) { // test build of the kernel: lists and walks must reproduce the full sequential scan
                 const HitInfo<F> full = sequential_closest_hit<F>(P, path, a, t_min);
@@ -1561,22 +1532,7 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
                     }
                 }
                 else {
-                    for (int p = 0; p < P.n_sph; ++p) {
-                        const SphereHot<F> g = P.sph_hot[p];
-                        refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, p, lb);
-                    }
-                    for (int q = 0; q < n_msph; ++q) {
-                        const MovingSphereRec<F> ms = P.msph[q];
-                        const V3<F> cen = msphere_center<F>(ms, path.tm);
-                        refine_sphere<F>(cen.x, cen.y, cen.z, ms.r2, path, a, t_min, msph_base + q, lb);
-                    }
-                    for (int q = 0; q < n_tri; ++q) {
-                        F tt;
-                        if (triangle_test<F, true>(P.tri[q], path, t_min, lb.t, tt)) {
-                            lb.t = tt;
-                            lb.idx = tri_base + q;
-                        }
-                    }
+                    lb = sequential_closest_hit<F>(P, path, a, t_min); // hittable_list.h:95-117, as it stands
                 }
                 done = shade<F>(P, lb, path, rng, radiance);
             }
@@ -1842,9 +1798,7 @@ template <typename F> __global__ void __launch_bounds__(256) deinterleave_kernel
     const uint64_t n = (uint64_t)S.row_values * (uint64_t)S.height;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t j = (uint32_t)(v / S.row_values), x = (uint32_t)(v - (uint64_t)j * S.row_values);
-        const uint32_t tile = j / S.tile_rows, r = tile % S.n_shards;
-        const uint32_t lr = (tile / S.n_shards) * S.tile_rows + (j - tile * S.tile_rows);
-        frame[v] = gathered[((uint64_t)S.row_off[r] + lr) * S.row_values + x];
+        frame[v] = gathered[(uint64_t)gather_source_row(S, j) * S.row_values + x];
     }
 }
 

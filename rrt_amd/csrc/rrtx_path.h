@@ -187,7 +187,11 @@ template <typename F> struct HitInfo {
 #define RRTX_SKIP_BEHIND 1 // 0: experiments (A/B of the early exit for spheres behind the origin)
 #endif
 // Exact per-candidate test, reference order.  Spheres: sphere.h:33-49.
-template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, HitInfo<F> &best)
+// AS_IT_STANDS: without the early exit for spheres behind the origin.  That exit is proven for FINITE operands only; the callers that
+// promise the reference's scan "as it stands" - sequential_closest_hit(), the fallback for rays outside the proven range, and the
+// VERIFY comparisons - take rays whose discriminant can be inf - inf = NaN, and the reference then ACCEPTS a NaN root (both
+// comparisons of sphere.h:43-48 are false for it), which the exit would turn into "no hit".
+template <typename F, bool AS_IT_STANDS = false> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const Path<F> &p, F a, F t_min, int idx, HitInfo<F> &best)
 {
     F ocx = p.o.x - cx, ocy = p.o.y - cy, ocz = p.o.z - cz;
     F half_b = ocx * p.d.x + ocy * p.d.y + ocz * p.d.z;
@@ -195,7 +199,7 @@ template <typename F> RRTX_DEV void refine_sphere(F cx, F cy, F cz, F r2, const 
     F disc = half_b * half_b - a * c;
     if (disc < 0) return;
 #if RRTX_SKIP_BEHIND
-    if (half_b > 0 && c > 0) return; // behind the origin: both roots are below t_min, sphere.h:43-48 rejects them whatever they are (see sphere_unordered)
+    if (!AS_IT_STANDS && half_b > 0 && c > 0) return; // behind the origin: both roots are below t_min, sphere.h:43-48 rejects them whatever they are (see sphere_unordered)
 #endif
     F sq = fsqrt(disc);
     F root = (-half_b - sq) / a;

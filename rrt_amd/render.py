@@ -201,7 +201,20 @@ class RrtGroup:
         self.params, self.fp64, self.devices = p, bool(fp64), devs
         self._g = C.c_void_p()
         arr = (C.c_int32 * len(devs))(*devs)
-        check(lib.rrtx_group_create(C.byref(p), len(devs), arr, _lib.GROUP_REHEARSAL if rehearsal else 0, C.byref(self._g)), "rrtx_group_create")
+        # RCCL greets on the process's stdout while the communicators are built; a host that owns stdout (bench.py prints its one
+        # JSON line there) keeps it clean itself - the library does not touch file descriptors (include/rrtx.h, ABI 4)
+        import os
+        import sys
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            rc = lib.rrtx_group_create(C.byref(p), len(devs), arr, _lib.GROUP_REHEARSAL if rehearsal else 0, C.byref(self._g))
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        check(rc, "rrtx_group_create")
         self.stats = None
         self._scene = None
 

@@ -50,6 +50,7 @@ struct rrtx_group {
 
 extern "C" {
 const char *rrtx_last_error(void) { return g_err.c_str(); }
+int rrtx_abi_version(void) { return RRTX_ABI_VERSION; }
 int rrtx_device_count(void) { return 2; }
 int rrtx_query(int device, rrtx_devinfo *out)
 {

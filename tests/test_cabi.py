@@ -52,6 +52,9 @@ def test_struct_sizes_match_the_header(tmp_path):
 
 def test_version_and_error_strings():
     assert _lib.lib.rrtx_version().decode().startswith("rrtx")
+    # the layout version a host checks before it hands the library its structs (advisor r03: the structs grew without one)
+    declared = int(re.search(r"#define\s+RRTX_ABI_VERSION\s+(\d+)", open(_lib.HEADER_PATH).read()).group(1))
+    assert _lib.lib.rrtx_abi_version() == declared == _lib.ABI_VERSION
     assert isinstance(_lib.lib.rrtx_last_error(), bytes)
 
 

@@ -67,3 +67,34 @@ def test_shard_rows_partition_the_frame():
                 for p in parts:
                     assert np.all(np.diff(p) > 0) if len(p) > 1 else True
                 assert max(len(p) for p in parts) - min(len(p) for p in parts) <= t
+
+
+def test_native_gather_plan_matches_the_definition_and_dist_shard_rows(tmp_path):
+    """rrtx_group's side of the multi-GPU path that no one-GPU box can run: the row-tile plan the library
+    compiles - how many rows a member renders, which frame row each of its local rows is, where a frame row lies in the
+    gathered buffer (rrt_amd/csrc/rrtx_device.h, shared by rrtx_api.cpp, the render kernel's comments and
+    deinterleave_kernel) - built for the host and checked for N = 1 .. 9 members, tiles of 1 .. 16 rows, ragged last tiles
+    and more members than tiles (1008 cases): shards disjoint and covering, counts equal to the definition, gather ->
+    de-interleave = identity; and every case's row lists equal rrt_amd.dist.shard_rows, the rule of the
+    one-process-per-GPU path."""
+    import subprocess
+
+    import numpy as np
+
+    from rrt_amd.dist import shard_rows
+    from _oracle import ROOT
+
+    exe = str(tmp_path / "gather_plan_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "gather_plan_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, "print"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "1008 cases ok" in r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1008
+    for line in lines:
+        head, body = line.split(":")
+        H, T, N = (int(x) for x in head.split())
+        parts = body.split("|")
+        assert len(parts) == N
+        for rank, part in enumerate(parts):
+            assert np.array_equal(np.array(part.split(), dtype=np.int64), shard_rows(H, rank, N, T)), (H, T, N, rank)
