@@ -57,6 +57,31 @@ template <typename F> void pack_unit(const F v[3], F out[3])
 // Term order (sphere half, ray half):  q in xx yy zz xy xz yz: (Q_h, N_h) (Q_h, N_l) (Q_l, N_h);  i in x y z: (c_h, b_h) (c_h, b_l) (c_l, b_h);
 // (1, g_h) (1, g_l);  (thr_h, -1) (thr_l, -1);  (0, 0).
 // ---------------------------------------------------------------------------------------------
+// The margins' budget (DESIGN.md 3a has the derivation, tests/test_filter_derivation.py holds every line against measurement), in units of
+// u S, u = 2^-24 (the unit roundoff of fp32), S = |o|^2 + |c|^2 + r^2.  A filter is safe iff its margin K u S covers the rounding error of
+// the reference's discriminant (sphere.h:35-41, per |d|^2) plus that of the filter's own value:
+constexpr int kBudgetRef = 42;               // the reference's discriminant in fp32: u |d|^2 (21 |o - c|^2 + 6 r^2), |o - c|^2 <= 2 (|o|^2 + |c|^2)   (fp64 rays: 2^-29 of that)
+constexpr int kBudgetIn64 = 16;              // fp64 rays: origin, direction and centres rounded to float before the fp32 filter sees them
+constexpr int kBudgetRay = 33;               // the ray's side in fp32: n = d / |d| (4.5 u a component), s = o.n (7.5 u |o|), b, g, the products n_i n_j
+constexpr int kBudgetVec = 11;               // vector form: c.n, the three FMAs over b.c + g, the last FMA
+constexpr int kBudgetMfSplit = 36;           // matrix form: operands as two f16 pieces (2^-22 each way), the low x low products dropped
+constexpr int kBudgetMfSum = 93;             // matrix form: 31 exact products added in f32, 30 roundings of a partial sum <= 3.003 lambda S, in any order
+constexpr int kBudgetMfUnderflowRay = 2;     // matrix form: f16 underflow (2^-25 absolute per piece) of the ray's pieces: 2 u S and 2e-7 absolute
+constexpr int kBudgetMfUnderflowSphere = 150; // matrix form: the same for a sphere's pieces - set aside; mf_sphere_stays_in_table() holds a sphere to it
+static_assert(kBudgetRef + kBudgetRay + kBudgetVec <= kFilterK, "vector form, fp32 rays");
+static_assert(kBudgetIn64 + kBudgetRay + kBudgetVec <= kFilterK64, "vector form, fp64 rays");
+static_assert(kBudgetRef + kBudgetRay + kBudgetMfSplit + kBudgetMfSum + kBudgetMfUnderflowRay + kBudgetMfUnderflowSphere <= kFilterKMf, "matrix form, fp32 rays");
+static_assert(kBudgetIn64 + kBudgetRay + kBudgetMfSplit + kBudgetMfSum + kBudgetMfUnderflowRay + kBudgetMfUnderflowSphere <= kFilterKMf64, "matrix form, fp64 rays");
+// A sphere's f16 pieces lose up to 2^-25 each to underflow, and that loss meets the ray's operands, which the kernel scales to under 2^14: per
+// unit of the scale lambda the error is 2^-25 U max(1, 2 m / 2^14), U the sum of the sphere's ten operands' magnitudes, m <= 1.0001 |o|^2 the
+// largest of the ray's.  It fits the share set aside for it - 150 u (|o|^2 + |c|^2 + r^2) and 9.8e-6 of the threshold's absolute term 1e-5 - iff
+//     2^-25 U <= 9.8e-6 + 150 u (|c|^2 + r^2)      (rays the kernel does not scale)       and       U <= 2.4e6      (rays it does).
+// A sphere that fails either is listed apart and tested exactly.  (Under the caps below - every operand within 60 000 - none does: the rule says so, not the caps.)
+inline bool mf_sphere_stays_in_table(long double operand_sum, long double c2, long double r2)
+{
+    return 0x1p-25L * operand_sum <= 9.8e-6L + (long double)kBudgetMfUnderflowSphere * 0x1p-24L * (c2 + r2) && operand_sum <= 2.4e6L;
+}
+
 inline uint16_t f32_to_f16_bits(float f) // round to nearest even; overflow -> inf; subnormals kept
 {
     uint32_t x;
@@ -117,6 +142,9 @@ template <typename F> inline void pack_mf_table(const std::vector<SphereHot<F>> 
             thr = (c2 - r2) - K * eps * (c2 + r2) - 1e-5L;
             for (int k = 0; k < 9; ++k) in_table = in_table && std::isfinite((double)v[k]) && std::fabs((double)v[k]) <= 60000.0;
             in_table = in_table && std::isfinite((double)thr) && std::fabs((double)thr) <= 60000.0 && (double)r2 >= 1e-3;
+            long double operand_sum = std::fabs((double)thr);
+            for (int k = 0; k < 9; ++k) operand_sum += std::fabs((double)v[k]);
+            in_table = in_table && mf_sphere_stays_in_table(operand_sum, c2, r2); // (the margin's derivation: see above)
             if (!in_table) out.big.push_back((uint32_t)i);
         }
         if (!in_table) { // a padding record, or a sphere listed apart: f = -60000 whatever the ray, never a candidate

@@ -161,7 +161,7 @@ def _population(rng, n, **kw):
         sin_plane = np.abs(_dot(nrm, d64)) / (area2 * n_d)
         shape = n_1 * n_2 / area2
     worst_case = EPS32 * n_s * n_d * n_1 * n_2 / 1e-7  # the model's lateral error at the cut, without its constant
-    return dict(ok=ok, miss=miss, scale=scale, cell=cell, sin_plane=sin_plane, shape=shape, worst_case=worst_case, cells_away=n_s / cell)
+    return dict(ok=ok, miss=miss, scale=scale, cell=cell, sin_plane=sin_plane, shape=shape, worst_case=worst_case, cells_away=n_s / cell, edge_ratio=(n_1 + n_2) / n_s)
 
 
 def test_the_float32_test_reports_hits_the_ray_passes_by_and_the_error_model_holds():
@@ -175,6 +175,27 @@ def test_the_float32_test_reports_hits_the_ray_passes_by_and_the_error_model_hol
         worst_c = max(worst_c, float((p["miss"][sel] / p["scale"][sel]).max()))
     assert n_ok > 300000 and n_miss > 20000  # accepted hits whose ray does NOT go through the triangle exist in float32 ...
     assert 0.5 < worst_c < C_MODEL, worst_c  # ... and are as large as the lateral error of (u, v) allows, not larger
+
+
+C_DERIVED_S, C_DERIVED_E = 24.0, 9.0  # the derived (first-order, worst-case) constants of the same model
+
+
+def test_the_derived_bound_of_the_lateral_error_holds_and_is_not_vacuous():
+    """DESIGN.md 3d derives, for the reference's Moeller-Trumbore test in fp32 (triangle.h:38-75 in rrtx_path.h's order, standard
+    model, first order):   |u^ - u| |e1| + |v^ - v| |e2|  <=  eps |d| |e1| |e2| / |a|  x  (24 |o - v0| + 9 (|e1| + |e2|)),
+    the distance by which an ACCEPTED pair's ray can pass the triangle.  It must hold on every hostile population (a violation
+    would be a wrong derivation), and the search must come within a sizeable fraction of it (C = 1.5 observed against 24: the
+    bound adds up absolute values of errors that mostly cancel).  The asserted C_MODEL = 8 of the searched rule sits between."""
+    rng = np.random.default_rng(37)
+    worst = 0.0
+    for kw in (dict(), dict(edge_aim=True, a_hi=30), dict(edge_aim=True, a_hi=30, size_lo=0.005, size_hi=0.3, dlen_hi=2.0), dict(a_hi=30, dist_lo=5.0), dict(edge_aim=True, a_hi=5, dist_lo=0.001, dist_hi=0.05)):
+        p = _population(rng, 1000000, **kw)
+        sel = p["ok"] & (p["miss"] > 0) & np.isfinite(p["scale"])
+        line = p["scale"][sel] * (C_DERIVED_S + C_DERIVED_E * p["edge_ratio"][sel])
+        assert np.all(p["miss"][sel] <= line), float((p["miss"][sel] / line).max())
+        worst = max(worst, float((p["miss"][sel] / line).max()))
+    assert 0.02 < worst <= 1.0, worst
+    assert C_SAFE < C_MODEL < C_DERIVED_S
 
 
 def test_no_miss_beyond_the_shipped_inflation_in_the_safe_set_and_misses_beyond_a_tenth_of_it():
