@@ -29,7 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields:
                  v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays), everything else - camera rays, exact tests, shading - on
                  the vector unit, and both are issued through the SIMD's one vector port: `achieved` = wave-instructions per
                  clock per SIMD with a matrix instruction counted as the 4 it keeps out (8 clocks), `peak` = 0.5 (one
-                 wave-instruction every second clock), `frac` = achieved / peak <= 1.  `roofline.mfma` prices the matrix
+                 wave-instruction every second clock), `frac` = achieved / peak (a model where matrix instructions are weighed, clamped to 1; the measured rates are beside it).  `roofline.mfma` prices the matrix
                  instructions alone against the dense f16 peak (2.5 PFLOP/s): the filter is a third of the kernel's cycles.
                  At N = 1 the counters come from rocprofv3 --pmc passes THIS run makes (SQ_INSTS_VALU & co. in one
                  pass, the matrix pipe's in another, FETCH_SIZE and WRITE_SIZE in passes of their own - the HBM `traffic`), on the `rrt` binary
@@ -232,14 +232,14 @@ def live_pmc(w, h, spp):
 
 def committed_pmc():
     """Fallback when no pass can be made here: the committed profile, only if it was measured on THIS device code."""
-    p = os.path.join(ROOT, "profiles", "r03_pmc_live.json")
+    p = os.path.join(ROOT, "profiles", "r04_pmc_live.json")
     try:
         d = json.load(open(p))
     except Exception:
         return None
     if d.get("kernel_source_sha") != kernel_source_hash():
         return None  # stale: the kernels changed since it was taken
-    d["source"] = "profiles/r03_pmc_live.json (committed; measured on the same device code: sha %s)" % d["kernel_source_sha"]
+    d["source"] = "profiles/r04_pmc_live.json (committed; measured on the same device code: sha %s)" % d["kernel_source_sha"]
     return d
 
 
@@ -571,9 +571,19 @@ def main():
             cyc = pmc["list_scan"]["GRBM_GUI_ACTIVE"] / 8.0
             mm = pmc.get("list_scan_mfma") or {}
             n_mfma = mm.get("SQ_INSTS_MFMA")
-            if n_mfma is not None:  # SQ_INSTS_VALU counts a matrix instruction once: weigh it by the issue clocks it holds
-                per_clk = (pmc["list_scan"]["SQ_INSTS_VALU"] + (MFMA_ISSUE - 1) * n_mfma) / (N_SIMD * cyc)
-            roof.update({"achieved": round(per_clk, 4), "frac": round(per_clk / VALU_PEAK, 4), "valu_lane_utilisation": round(lanes, 4) if lanes else None,
+            raw_per_clk = per_clk  # SQ_INSTS_VALU / clk / SIMD as counted (a matrix instruction counts once)
+            mfma_per_clk = None
+            if n_mfma is not None:
+                # SQ_INSTS_VALU counts a matrix instruction once, but it holds the port for MFMA_ISSUE plain instructions' clocks: a MODEL, from two
+                # separate passes - each rate is formed with ITS OWN pass's clock count (runs differ in clock and duration), then added
+                mfma_per_clk = n_mfma / (N_SIMD * (mm["GRBM_GUI_ACTIVE"] / 8.0))
+                per_clk = raw_per_clk + (MFMA_ISSUE - 1) * mfma_per_clk
+            roof.update({"achieved": round(per_clk, 4), "frac": round(min(1.0, per_clk / VALU_PEAK), 4), "modelled": n_mfma is not None,
+                         "measured": {"valu_instructions_per_clk_per_simd": round(raw_per_clk, 4), "mfma_instructions_per_clk_per_simd": round(mfma_per_clk, 5) if mfma_per_clk is not None else None,
+                                      "mfma_issue_weight": MFMA_ISSUE,
+                                      "note": "achieved = valu + (weight - 1) x mfma: the two rates are MEASURED (separate PMC passes, each over its own GRBM_GUI_ACTIVE / 8), the weight - a matrix "
+                                              "instruction holds the vector issue port for 8 clocks, a plain one for 2 (MI355X_MICROARCH.md, cycle constants) - is a constant of the model; frac is clamped to 1"},
+                         "valu_lane_utilisation": round(lanes, 4) if lanes else None,
                          "shader_clock_GHz": round(ghz, 3) if ghz else None, "counters": {k: v for k, v in pmc["list_scan"].items() if k != "kernel_name"}, "source": pmc["source"], "kernel_source_sha": pmc.get("kernel_source_sha")})
             if n_mfma is not None:
                 mcyc = mm["GRBM_GUI_ACTIVE"] / 8.0
@@ -610,7 +620,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: scenes/final.txt %dx%d spp=%d d=%d fp32, brute-force list scan (488 spheres)" % (wl_name, W, H, spp, DEPTH),
+            "config": {"workload": "%s: scenes/final.txt %dx%d spp=%d d=%d fp32, list scan of 488 spheres (-b; camera rays via per-pixel candidate lists, every other segment through the whole list)" % (wl_name, W, H, spp, DEPTH),
                        "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", one RCCL gather to rank 0 per step" if world > 1 else ""),
                        "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests),
                        "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
