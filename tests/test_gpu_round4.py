@@ -1,0 +1,63 @@
+"""Round 4's additions to the product, on the GPU: the convergence-fault counter of the wave-wide steps, the struct layout
+version, and that destroying a context gives every device buffer back (advisor r03: the matrix form's operand tables leaked)."""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from _oracle import Oracle, mesh_scene, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_no_wave_reaches_a_wave_wide_step_short_of_lanes(gpu):
+    """dense_candidates (prefix sums by DPP, the read of lane 63, fourteen bpermutes) and the matrix-core scan take operands from
+    every lane of the wave: they check EXEC on entry and count a fault instead of assuming convergence (rrtx_stats.convergence_faults,
+    which rrtx_collect turns into an error).  Every variant that has such a step, both precisions, frames against the oracle."""
+    mesh = mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), 12, 24)[0]
+    cases = [(scene_path("final"), False, "scan_mfma"), (scene_path("final"), True, None), (mesh, True, "walk_pairs"), (scene_path("test3"), True, "walk_pairs")]
+    for path, bvh, marker in cases:
+        for fp64 in (False, True):
+            w, h, spp = 96, 64, 8
+            r = gpu.Rrt(w, h, spp, 50, use_bvh=bvh, fp64=fp64)
+            fb = r.render(gpu.Scene(path, w, h, fp64=fp64))
+            st = dict(r.stats)
+            r.close()
+            assert st["convergence_faults"] == 0
+            if marker:
+                assert st[marker] > 0, (path, marker)  # (the variant with the wave-wide step is the one that ran)
+            if st["accel_exact"]:  # (an fp32 mesh is gridded under the stated tolerance: tests/test_gpu_mesh.py bounds that)
+                want, so = Oracle(path, w, h, fp64).render(spp, 50, 1984, order=1, chunk=8)
+                assert np.array_equal(fb, want) and st["segments"] == so["segments"]
+
+
+def test_struct_layout_version_is_checked_by_the_binding(gpu):
+    from rrt_amd import _lib
+
+    assert _lib.lib.rrtx_abi_version() == _lib.ABI_VERSION == 4
+    assert C.sizeof(_lib.Stats) % 8 == 0 and "convergence_faults" in dict(_lib.Stats._fields_)
+
+
+def test_destroying_a_context_returns_its_device_memory(gpu):
+    """A batch worker creates and destroys contexts by the hundred; every scene buffer - the matrix form's f16 table and its list
+    of spheres kept apart among them (leaked up to round 3) - must be freed with the context."""
+    import torch
+
+    sc = gpu.Scene(scene_path("final"), 64, 48)
+
+    def cycle(n):
+        for _ in range(n):
+            r = gpu.Rrt(64, 48, 2, 8, use_bvh=False)
+            r.render(sc)
+            assert r.stats["scan_mfma"] == 1
+            r.close()
+
+    cycle(5)  # (the runtime's own pools settle)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(200)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 4 << 20, "device memory shrank by %d bytes over 200 create / render / destroy cycles" % (free0 - free1)
