@@ -175,6 +175,10 @@ typedef struct rrtx_params {
  * instead of the matrix cores (two chained v_mfma_f32_32x32x16_f16 per 32 spheres x 32 rays; A/B switch, identical images). */
 #define RRTX_FLAG_SCAN_NO_MFMA 256
 
+/* sample_chunk = -1 (the reference's own order of summation): schedule it as ONE work item per pixel, as up to ABI 3, instead of small work items
+ * that store every sample for a final running sum (A/B switch; the images are identical, the one-item schedule takes about twice the time). */
+#define RRTX_FLAG_ONE_ITEM_PER_PIXEL 512
+
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
                                 render, measured on the stream they were launched on         */

@@ -58,6 +58,8 @@ struct rrtx_ctx {
     // derived geometry of this shard
     int local_rows = 0;
     int chunk = 0, chunks_per_pixel = 0;
+    int sum_chunk = 0;        // the summation shape the image has (rrtx_stats.sample_chunk): == chunk, except in per-sample launches, where the tasks (chunk) are small
+    bool per_sample = false;  // every sample's radiance stored by itself, summed by finalize_kernel in chunks of sum_chunk (sample_chunk = -1 at spp > 16: the reference's order)
     uint32_t total_tasks = 0;
     uint32_t taper_pixel = 0; // first local pixel cut into single-sample tasks
     bool use_partial = false; // tasks write partial sums, finalize_kernel forms the frame
@@ -249,7 +251,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
     memcpy(&P.cam, c->cam_bytes, sizeof(CameraRec<F>));
     P.W = c->p.image_width, P.H = c->p.image_height, P.spp = c->p.samples_per_pixel, P.max_depth = c->p.max_depth;
     P.seed = c->p.seed;
-    P.chunk = c->chunk, P.chunks_per_pixel = c->chunks_per_pixel;
+    P.chunk = c->chunk, P.chunks_per_pixel = c->chunks_per_pixel, P.per_sample = c->per_sample ? 1 : 0;
     P.local_rows = c->local_rows;
     P.tile_rows = c->p.tile_rows, P.shard_rank = c->p.shard_rank, P.shard_count = c->p.shard_count;
     P.taper_pixel = c->taper_pixel, P.taper_task_base = c->taper_pixel * (uint32_t)c->chunks_per_pixel;
@@ -414,6 +416,13 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
         }
         if (chunk > p.samples_per_pixel) chunk = p.samples_per_pixel;
     }
+    // One work item per pixel (the reference's own order of summation: one running sum over all samples, rrt.cu:115) is a schedule of 500-sample items: twice
+    // the time of 8-sample ones (98.5 against 48.9 ms on configuration 3).  The order does not need the schedule: the tasks stay small and write every sample's
+    // radiance to its own slot ([pixel][sample][3]: 12 bytes a sample, 5.8 GB for 1200x800 spp 500), finalize_kernel adds a pixel's samples up in one running sum.
+    c->sum_chunk = chunk;
+    c->per_sample = chunk == p.samples_per_pixel && p.samples_per_pixel > 16 && !(p.flags & RRTX_FLAG_ONE_ITEM_PER_PIXEL) &&
+                    (int64_t)c->local_rows * p.image_width * p.samples_per_pixel * 3 * (int64_t)c->fsize <= ((int64_t)96 << 30);
+    if (c->per_sample) chunk = 8;
     c->chunk = chunk;
     c->chunks_per_pixel = (p.samples_per_pixel + chunk - 1) / chunk;
     // the last `taper` samples of the queue go out as single-sample tasks (task_decode in rrtx_kernels.hip)
@@ -421,7 +430,7 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     hipError_t e = hipGetDeviceProperties(&prop, p.device);
     const int64_t local_pixels = (int64_t)c->local_rows * p.image_width;
     int64_t taper = p.taper_samples > 0 ? p.taper_samples : (p.taper_samples < 0 || e != hipSuccess ? 0 : kTaperSamplesPerCu * prop.multiProcessorCount);
-    if (chunk <= 1) taper = 0;
+    if (chunk <= 1 || c->per_sample) taper = 0;
     int64_t tapered_pixels = (taper + p.samples_per_pixel - 1) / p.samples_per_pixel;
     if (tapered_pixels > local_pixels) tapered_pixels = local_pixels;
     const int64_t tasks = (local_pixels - tapered_pixels) * c->chunks_per_pixel + tapered_pixels * p.samples_per_pixel;
@@ -441,7 +450,7 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     if (e == hipSuccess && c->use_partial) {
         // (footprint: one vec3 per work item - 0.73 GB for 1200x800 spp 500, 6.3 GB fp32 / 12.5 GB fp64 for 3840x2160 spp 1000 at
         // 16 samples per item; several contexts on one device each hold their own)
-        const size_t bytes = (size_t)c->total_tasks * 3 * c->fsize + 64;
+        const size_t bytes = (c->per_sample ? (size_t)local_pixels * (size_t)p.samples_per_pixel : (size_t)c->total_tasks) * 3 * c->fsize + 64;
         e = hipMalloc(&c->d_partial, bytes);
         if (e != hipSuccess) {
             char buf[384];
@@ -611,7 +620,11 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->use_partial ? c->d_partial : d_rows;
-    const FinalizeShape shape = {(uint32_t)((size_t)c->local_rows * c->p.image_width), c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel};
+    // a running sum over all of a pixel's samples IS the staged form with every sample a "chunk sum" of its own: 0 + r0 + r1 + ... (the reference adds to a zeroed
+    // pixel_color, rrt.cu:110-115)
+    const uint32_t n_px = (uint32_t)((size_t)c->local_rows * c->p.image_width);
+    const FinalizeShape shape = c->per_sample ? FinalizeShape{n_px, n_px, c->p.samples_per_pixel, 1, c->p.samples_per_pixel, 0}
+                                              : FinalizeShape{n_px, c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel, 0};
     // The launches of one render.  If one of them fails after an earlier one was enqueued, that kernel may still be reading the
     // scene's tables while the caller, holding an error, goes on to rrtx_set_scene (which waits for stop EVENTS only, and none
     // will have been recorded): the stream is drained before the error is returned.
@@ -711,7 +724,7 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         }
         stats->grid_blocks = c->grid_blocks;
         stats->block_threads = (!c->accel && c->use_filter && c->lds_mode == 3) ? mf_block_threads(c->fsize) : kBlockThreads;
-        stats->sample_chunk = c->chunk;
+        stats->sample_chunk = c->sum_chunk; // (the summation shape; per-sample launches schedule in tasks of c->chunk)
         stats->accel_cells = c->accel ? c->n_grid_cells : 0;
         stats->accel_exact = c->accel ? (c->accel_exact ? 1 : 0) : 1;
         stats->local_rows = c->local_rows;

@@ -170,6 +170,9 @@ template <typename F> struct KernelParams {
     uint32_t seed;
     int32_t chunk;           // samples per task
     int32_t chunks_per_pixel;
+    int32_t per_sample;      // 1: a task does not add its samples up - every sample's radiance goes to out[(pixel * spp + sample) * 3] and finalize_kernel adds a
+                             // pixel's samples in the ORDER ASKED FOR (the reference's: one running sum, rrt.cu:115), whatever the tasks' size.  That is how
+                             // sample_chunk = -1 runs at the speed of 8-sample work items instead of one 500-sample item per pixel.
     // shard: local row lr -> global row ((lr / tile_rows) * shard_count + shard_rank) * tile_rows + lr % tile_rows
     int32_t local_rows, tile_rows, shard_rank, shard_count;
     FastDiv div_cpp, div_spp, div_w, div_tile; // chunks_per_pixel, spp, W, tile_rows
@@ -202,6 +205,7 @@ template <typename F> struct KernelParams {
 struct FinalizeShape {
     uint32_t n_pixels, taper_pixel; // local pixels; first single-sample pixel
     int32_t chunks_per_pixel, chunk, spp;
+    int32_t group;                  // pixels a block stages at a time (their slabs fit the kernel's LDS)
 };
 
 // shape of a multi-device gather, for deinterleave_kernel (rrtx_group.cpp)

@@ -155,6 +155,35 @@ RRTX_DEV void load_unit(const KernelParams<F> &P, uint32_t u, uint32_t &task, in
     out_index = item * (uint32_t)kTailSplit + k;
 }
 
+// A sample's radiance is known: rrt.cu:115, `pixel_color += ray_color(...)`, then the next sample or the end of the task.
+// per_sample launches (the reference's own summation order at the speed of small work items): nothing is added here - the sample's
+// radiance goes to its own slot, [pixel][sample][3], and finalize_kernel forms the pixel's running sum in sample order.
+template <typename F, bool RESUME> RRTX_DEV void finish_sample(const KernelParams<F> &P, const V3<F> &radiance, uint32_t task, int &s_cur, int s_end, bool single, uint32_t out_index, V3<F> &acc, bool &need_task, bool &need_ray)
+{
+    const auto &C = *cold_params<F>();
+    if (C.per_sample) {
+        F *o = C.out + ((size_t)task_pixel<F>(C, task) * (size_t)C.spp + (size_t)s_cur) * 3;
+        o[0] = radiance.x, o[1] = radiance.y, o[2] = radiance.z;
+        s_cur += 1;
+        if (s_cur == s_end)
+            need_task = true;
+        else
+            need_ray = true;
+        return;
+    }
+    acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance);
+    s_cur += 1;
+    if (s_cur == s_end) {
+        F *o = RESUME ? P.tail_rad + (size_t)out_index * 3 : task_slot<F>(C, task);
+        o[0] = acc.x;
+        o[1] = acc.y;
+        o[2] = acc.z;
+        need_task = true;
+    }
+    else
+        need_ray = true;
+}
+
 // Records the scan reads: the fp32 filter table, or (FILTER = false) the exact-test table in F.
 template <typename F, bool FILTER> struct ScanType {
     typedef F type;
@@ -1170,19 +1199,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             } // max_depth > 0
 
             RRTX_SEC(6); // sample / task bookkeeping, stores
-            if (done) {
-                acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
-                s_cur += 1;
-                if (s_cur == s_end) {
-                    F *o = RESUME ? P.tail_rad + (size_t)out_index * 3 : task_slot<F>(*cold_params<F>(), task);
-                    o[0] = acc.x;
-                    o[1] = acc.y;
-                    o[2] = acc.z;
-                    need_task = true;
-                }
-                else
-                    need_ray = true;
-            }
+            if (done) finish_sample<F, RESUME>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
         }
         } // !kDensePairs
         else {
@@ -1301,19 +1318,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             RRTX_SEC(5);
             if (resolved) done = shade<F, SO>(P, best, path, rng, radiance);
             RRTX_SEC(6); // sample / task bookkeeping, stores
-            if (done) {
-                acc = (RESUME && single) ? radiance : vadd<F>(acc, radiance); // rrt.cu:115 pixel_color +=
-                s_cur += 1;
-                if (s_cur == s_end) {
-                    F *o = RESUME ? P.tail_rad + (size_t)out_index * 3 : task_slot<F>(*cold_params<F>(), task);
-                    o[0] = acc.x;
-                    o[1] = acc.y;
-                    o[2] = acc.z;
-                    need_task = true;
-                }
-                else
-                    need_ray = true;
-            }
+            if (done) finish_sample<F, RESUME>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
         }
     }
 
@@ -1537,11 +1542,18 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
                 done = shade<F>(P, lb, path, rng, radiance);
             }
             if (done) {
-                acc = single ? radiance : vadd<F>(acc, radiance); // units k >= 1 deliver the sample itself
+                if (P.per_sample) { // (every sample to its own slot: finalize_kernel adds them up)
+                    if (sub == 0) {
+                        F *o = P.out + ((size_t)task_pixel<F>(P, task) * (size_t)P.spp + (size_t)s_cur) * 3;
+                        o[0] = radiance.x, o[1] = radiance.y, o[2] = radiance.z;
+                    }
+                }
+                else
+                    acc = single ? radiance : vadd<F>(acc, radiance); // units k >= 1 deliver the sample itself
                 s_cur += 1;
                 need_ray = true;
                 if (s_cur >= s_end) {
-                    if (sub == 0) {
+                    if (sub == 0 && !P.per_sample) {
                         F *o = P.tail_rad + (size_t)out_index * 3;
                         o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
                     }
@@ -1577,6 +1589,7 @@ template <typename F, int G, bool LDS, bool FILTER> __global__ void __launch_bou
 // and stores the task's partial sum.  One thread per item.
 template <typename F> __global__ void __launch_bounds__(256) tail_sum_kernel(const KernelParams<F> P)
 {
+    if (P.per_sample) return; // (the units stored their samples themselves: there are no per-task sums)
     const uint32_t n_items = *P.tail_count;
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += gridDim.x * blockDim.x) {
         const TailItem<F> it = P.tail_items[item];
@@ -1747,10 +1760,11 @@ template <typename F, bool STAGED> __global__ void __launch_bounds__(256) finali
     if (STAGED) {
         F *const slab = (F *)dyn_lds;
         const uint32_t per_pixel = (uint32_t)S.chunks_per_pixel * 3u;
-        const uint32_t n_groups = (S.taper_pixel + kFinalizeGroup - 1) / kFinalizeGroup;
+        const uint32_t group = (uint32_t)S.group;
+        const uint32_t n_groups = (S.taper_pixel + group - 1) / group;
         for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-            const uint32_t q0 = g * kFinalizeGroup;
-            const uint32_t n_px = S.taper_pixel - q0 < (uint32_t)kFinalizeGroup ? S.taper_pixel - q0 : (uint32_t)kFinalizeGroup;
+            const uint32_t q0 = g * group;
+            const uint32_t n_px = S.taper_pixel - q0 < group ? S.taper_pixel - q0 : group;
             const F *src = partial + (size_t)q0 * per_pixel;
             for (uint32_t i = threadIdx.x; i < n_px * per_pixel; i += blockDim.x) slab[i] = src[i];
             __syncthreads();
@@ -1879,11 +1893,16 @@ template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filt
 }
 template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const FinalizeShape &S, hipStream_t stream)
 {
-    const size_t slab = (size_t)kFinalizeGroup * (size_t)S.chunks_per_pixel * 3 * sizeof(F);
-    if (S.taper_pixel > 0 && S.chunks_per_pixel > 1 && slab <= kFinalizeLdsBytes) {
-        uint32_t blocks = (S.taper_pixel + kFinalizeGroup - 1) / kFinalizeGroup;
-        if (blocks > 8192u) blocks = 8192u;
-        hipLaunchKernelGGL((finalize_kernel<F, true>), dim3(blocks), dim3(256), slab, stream, partial, fb, S);
+    // (as many pixels per block as fit the LDS budget, 16 at the most: 16 for 63 chunk sums a pixel, 8 / 4 for 500 samples a pixel in fp32 / fp64)
+    const size_t per_pixel = (size_t)S.chunks_per_pixel * 3 * sizeof(F);
+    int group = per_pixel ? (int)(kFinalizeLdsBytes / per_pixel) : 0;
+    if (group > kFinalizeGroup) group = kFinalizeGroup;
+    if (S.taper_pixel > 0 && S.chunks_per_pixel > 1 && group >= 1) {
+        FinalizeShape G = S;
+        G.group = group;
+        uint32_t blocks = (S.taper_pixel + (uint32_t)group - 1) / (uint32_t)group;
+        if (blocks > 16384u) blocks = 16384u;
+        hipLaunchKernelGGL((finalize_kernel<F, true>), dim3(blocks), dim3(256), (size_t)group * per_pixel, stream, partial, fb, G);
         return hipGetLastError();
     }
     int blocks = (int)((S.n_pixels * 3u + 255u) / 256u);

@@ -17,7 +17,7 @@ def test_no_wave_reaches_a_wave_wide_step_short_of_lanes(gpu):
     every lane of the wave: they check EXEC on entry and count a fault instead of assuming convergence (rrtx_stats.convergence_faults,
     which rrtx_collect turns into an error).  Every variant that has such a step, both precisions, frames against the oracle."""
     mesh = mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), 12, 24)[0]
-    cases = [(scene_path("final"), False, "scan_mfma"), (scene_path("final"), True, None), (mesh, True, "walk_pairs"), (scene_path("test3"), True, "walk_pairs")]
+    cases = [(scene_path("final"), False, "scan_mfma"), (scene_path("final"), True, None), (mesh, True, "walk_pairs"), (scene_path("test3"), True, None)]  # (test3: four primitives - no grid, scanned also under use_bvh)
     for path, bvh, marker in cases:
         for fp64 in (False, True):
             w, h, spp = 96, 64, 8
@@ -61,3 +61,40 @@ def test_destroying_a_context_returns_its_device_memory(gpu):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 4 << 20, "device memory shrank by %d bytes over 200 create / render / destroy cycles" % (free0 - free1)
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_reference_summation_order_at_the_speed_of_small_work_items(gpu, fp64):
+    """sample_chunk = -1 asks for the reference's own order of summation (one running sum per pixel, rrt.cu:115).  Up to round 3 that
+    was a SCHEDULE - one 500-sample work item per pixel, twice the time; since round 4 the work items stay small, every sample's
+    radiance goes to its own slot and finalize_kernel forms the running sum.  Same bits as the one-item schedule
+    (RRTX_FLAG_ONE_ITEM_PER_PIXEL) and as the oracle without any `chunk=`; both closest-hit modes, a shard, a hand-off that parks
+    most of the launch, a mesh (the dense variants and their resume pass)."""
+    f, w, h, spp = scene_path("final"), 120, 80, 40
+    want, so = Oracle(f, w, h, fp64).render(spp, 50, 1984, order=1)  # (the oracle's default: the reference's order)
+    sc = gpu.Scene(f, w, h, fp64=fp64)
+    for kw in (dict(use_bvh=False), dict(use_bvh=True), dict(use_bvh=False, handoff_lanes=64, handoff_iters=1), dict(use_bvh=True, flags=gpu.FLAG_NO_TAIL_GRID),
+               dict(use_bvh=False, flags=gpu.FLAG_NO_TAIL_GRID | gpu.FLAG_SCAN_NO_MFMA, handoff_lanes=64, handoff_iters=1)):
+        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=-1, **kw)
+        fb = r.render(sc)
+        st = dict(r.stats)
+        r.close()
+        assert st["sample_chunk"] == spp and st["segments"] == so["segments"]
+        assert np.array_equal(fb, want), kw
+    one = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=-1, flags=gpu.FLAG_ONE_ITEM_PER_PIXEL)
+    assert np.array_equal(one.render(sc), want)
+    one.close()
+    # a shard of the frame (rows of tiles 1, 3, 5 ... of 2 rows)
+    r = gpu.Rrt(w, h, spp, 50, fp64=fp64, sample_chunk=-1, shard_rank=1, shard_count=2, tile_rows=2)
+    fb = r.render(sc)
+    rows = r.shard_rows()
+    r.close()
+    assert np.array_equal(fb[rows], want[rows])
+    # a mesh through the densely pairing variants (fp64: the grid is exact there)
+    if fp64:
+        mesh = mesh_scene(os.path.join(tempfile.mkdtemp(), "mesh.txt"), 8, 16)[0]
+        mw, mh, ms = 64, 48, 24
+        want_m, _ = Oracle(mesh, mw, mh, True).render(ms, 50, 1984, order=1)
+        r = gpu.Rrt(mw, mh, ms, 50, fp64=True, sample_chunk=-1, use_bvh=True)
+        assert np.array_equal(r.render(gpu.Scene(mesh, mw, mh, fp64=True)), want_m)
+        r.close()
