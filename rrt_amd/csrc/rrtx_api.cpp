@@ -620,11 +620,8 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     const int slot = c->ev_pending;
     RRTX_HIP(hipEventRecord(c->ev_start[slot], st));
     void *out = c->use_partial ? c->d_partial : d_rows;
-    // a running sum over all of a pixel's samples IS the staged form with every sample a "chunk sum" of its own: 0 + r0 + r1 + ... (the reference adds to a zeroed
-    // pixel_color, rrt.cu:110-115)
     const uint32_t n_px = (uint32_t)((size_t)c->local_rows * c->p.image_width);
-    const FinalizeShape shape = c->per_sample ? FinalizeShape{n_px, n_px, c->p.samples_per_pixel, 1, c->p.samples_per_pixel, 0}
-                                              : FinalizeShape{n_px, c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel, 0};
+    const FinalizeShape shape = {n_px, c->taper_pixel, c->chunks_per_pixel, c->chunk, c->p.samples_per_pixel, 0, c->per_sample ? 1 : 0};
     // The launches of one render.  If one of them fails after an earlier one was enqueued, that kernel may still be reading the
     // scene's tables while the caller, holding an error, goes on to rrtx_set_scene (which waits for stop EVENTS only, and none
     // will have been recorded): the stream is drained before the error is returned.

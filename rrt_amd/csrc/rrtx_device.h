@@ -206,6 +206,7 @@ struct FinalizeShape {
     uint32_t n_pixels, taper_pixel; // local pixels; first single-sample pixel
     int32_t chunks_per_pixel, chunk, spp;
     int32_t group;                  // pixels a block stages at a time (their slabs fit the kernel's LDS)
+    int32_t per_sample;             // 1: `partial` holds every sample, [pixel][sample][3]; the frame is one running sum per pixel (finalize_samples_kernel)
 };
 
 // shape of a multi-device gather, for deinterleave_kernel (rrtx_group.cpp)

@@ -1803,6 +1803,48 @@ template <typename F, bool STAGED> __global__ void __launch_bounds__(256) finali
     }
 }
 
+// Per-sample launches (KernelParams::per_sample): `samples` holds every sample's radiance, [pixel][sample][3]; a pixel's value is ONE running sum over its
+// samples in sample order - rrt.cu:110-115: pixel_color(0, 0, 0), then += per sample.  A chain of spp dependent additions per (pixel, channel), 2.9 M chains for
+// a 1200x800 frame: every thread of a block owns one chain (85 pixels x 3 channels to a block of 256) and keeps its running sum in a register while the block
+// streams the pixels' samples through LDS in slices of T samples - a contiguous T x 12 bytes per pixel and slice, loaded with coalesced 4-byte accesses by all
+// threads - and within a slice the values are read eight ahead of the eight additions that take them.  (The first version staged 8 whole pixels per block and ran
+// 24 chains on 256 threads, each addition behind its own LDS read: 3.9 ms for the 5.8 GB of configuration 3; this form is bound by the read of that buffer.)
+constexpr int kSampleChainPixels = 85;
+template <typename F> __global__ void __launch_bounds__(256) finalize_samples_kernel(const F *__restrict__ samples, F *__restrict__ fb, uint32_t n_pixels, int spp, int slice)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    F *const slab = (F *)dyn_lds; // [pixel of the group][sample of the slice][3]
+    for (uint32_t q0 = blockIdx.x * (uint32_t)kSampleChainPixels; q0 < n_pixels; q0 += gridDim.x * (uint32_t)kSampleChainPixels) {
+        const uint32_t n_px = n_pixels - q0 < (uint32_t)kSampleChainPixels ? n_pixels - q0 : (uint32_t)kSampleChainPixels;
+        const uint32_t q = threadIdx.x / 3u, ch = threadIdx.x - q * 3u; // this thread's chain (threads 255 and those of absent pixels only help loading)
+        const bool mine = q < n_px;
+        F s = 0;
+        for (int t0 = 0; t0 < spp; t0 += slice) {
+            const int nt = spp - t0 < slice ? spp - t0 : slice;
+            const uint32_t per_px = (uint32_t)nt * 3u;
+            for (uint32_t i = threadIdx.x; i < n_px * per_px; i += 256u) {
+                const uint32_t pq = i / per_px, r = i - pq * per_px;
+                slab[pq * (uint32_t)slice * 3u + r] = samples[((size_t)(q0 + pq) * (size_t)spp + (size_t)t0) * 3 + r];
+            }
+            __syncthreads();
+            if (mine) {
+                const F *p = slab + q * (uint32_t)slice * 3u + ch;
+                int t = 0;
+                for (; t + 8 <= nt; t += 8) {
+                    F v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = p[(t + j) * 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s = s + v[j];
+                }
+                for (; t < nt; ++t) s = s + p[t * 3];
+            }
+            __syncthreads();
+        }
+        if (mine) fb[(size_t)(q0 + q) * 3 + ch] = s;
+    }
+}
+
 // Multi-device gather, last step (rrtx_group.cpp): `gathered` holds the compact row blocks of the N shards
 // side by side (shard r from row GatherShape::row_off[r] on, its rows in ascending order); the frame's row j
 // belongs to shard (j / T) mod N, where it is local row (j / (T N)) T + j mod T.  One thread per value; pure
@@ -1893,6 +1935,14 @@ template <typename F> hipError_t launch_tail(const KernelParams<F> &P, bool filt
 }
 template <typename F> hipError_t launch_finalize(const F *partial, F *fb, const FinalizeShape &S, hipStream_t stream)
 {
+    if (S.per_sample) { // one running sum per pixel over its samples, [pixel][sample][3]
+        const int slice = (int)(kFinalizeLdsBytes / ((size_t)kSampleChainPixels * 3 * sizeof(F))); // 48 samples in fp32, 24 in fp64
+        uint32_t blocks = (S.n_pixels + kSampleChainPixels - 1) / kSampleChainPixels;
+        if (blocks > 16384u) blocks = 16384u;
+        if (blocks < 1u) blocks = 1u;
+        hipLaunchKernelGGL(finalize_samples_kernel<F>, dim3(blocks), dim3(256), (size_t)kSampleChainPixels * slice * 3 * sizeof(F), stream, partial, fb, S.n_pixels, S.spp, slice);
+        return hipGetLastError();
+    }
     // (as many pixels per block as fit the LDS budget, 16 at the most: 16 for 63 chunk sums a pixel, 8 / 4 for 500 samples a pixel in fp32 / fp64)
     const size_t per_pixel = (size_t)S.chunks_per_pixel * 3 * sizeof(F);
     int group = per_pixel ? (int)(kFinalizeLdsBytes / per_pixel) : 0;
