@@ -179,6 +179,10 @@ typedef struct rrtx_params {
  * that store every sample for a final running sum (A/B switch; the images are identical, the one-item schedule takes about twice the time). */
 #define RRTX_FLAG_ONE_ITEM_PER_PIXEL 512
 
+/* Keep the pixels whose camera-ray candidate list is empty - sky in every sample - in the render kernel's queue instead of finishing their work items in a dense
+ * kernel of their own (A/B switch; the images are identical). */
+#define RRTX_FLAG_NO_SKY_SPLIT 1024
+
 typedef struct rrtx_stats {
     double kernel_ms;        /* HIP-event time of the render (+finalise) kernels of the LAST
                                 render, measured on the stream they were launched on         */

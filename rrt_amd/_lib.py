@@ -204,6 +204,7 @@ FLAG_EXACT_ACCEL = 64
 FLAG_NO_TAIL_GRID = 128
 FLAG_SCAN_NO_MFMA = 256
 FLAG_ONE_ITEM_PER_PIXEL = 512
+FLAG_NO_SKY_SPLIT = 1024
 
 
 class RrtxError(RuntimeError):

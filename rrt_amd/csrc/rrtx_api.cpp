@@ -80,6 +80,9 @@ struct rrtx_ctx {
     void *d_partial = nullptr; // [total_tasks][3] unless every pixel is a single task
     uint16_t *d_plist = nullptr;  // camera-ray candidate lists [local pixel][kPlistStride]
     bool have_plist = false;      // ... valid for the current scene (the buffer itself is kept from scene to scene)
+    uint32_t *d_order = nullptr, *d_order_scratch = nullptr; // the sky split (KernelParams::pixel_order): the pixels with a non-empty list first ...
+    uint32_t n_queue_pixels = 0;  // ... this many of them
+    bool have_split = false;
     // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
     bool accel = false;
     bool tail_grid = false;   // list scan (-b), but what a launch parks at its end is finished through the grid (a RESUME pass: same bits)
@@ -274,6 +277,10 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
         memcpy(&P.grid, c->grid_bytes, sizeof(GridRec<F>));
     }
     P.plist = c->have_plist ? c->d_plist : nullptr;
+    if (c->have_split) {
+        P.pixel_order = c->d_order, P.n_queue_pixels = c->n_queue_pixels;
+        P.total_tasks = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel; // the render kernel's queue; sky_tasks_kernel takes the positions behind it
+    }
     P.list_passes = c->have_plist ? (c->p.list_passes > 0 ? c->p.list_passes : (c->p.list_passes < 0 ? 0 : kListPasses)) : 0;
     P.verify_lists = (c->p.flags & RRTX_FLAG_VERIFY_LISTS) ? 1 : 0;
     P.diag = nullptr;
@@ -287,13 +294,13 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
 void free_scene_buffers(rrtx_ctx *c)
 {
     void **bufs[] = {&c->d_hot, &c->d_filter, &c->d_cold, &c->d_msph, &c->d_tri, &c->d_tri_scan, &c->d_mat, (void **)&c->d_grid_cell_start, (void **)&c->d_grid_cell_prims,
-                     (void **)&c->d_grid_always, (void **)&c->d_mf_table, (void **)&c->d_mf_big, (void **)&c->d_plist, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
+                     (void **)&c->d_grid_always, (void **)&c->d_mf_table, (void **)&c->d_mf_big, (void **)&c->d_plist, (void **)&c->d_order, (void **)&c->d_order_scratch, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
     for (void **b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
     }
     c->caps.clear();
-    c->have_scene = c->have_plist = false;
+    c->have_scene = c->have_plist = c->have_split = false;
     c->accel = c->tail_grid = false;
     c->tail_capacity = 0;
 }
@@ -549,7 +556,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
     // camera-ray candidate lists (one pre-pass per scene: they depend on the camera and the spheres)
-    c->have_plist = false;
+    c->have_plist = c->have_split = false;
     // (a LIST pass tests every moving sphere and triangle per camera ray, with the few lanes that hold one: with a
     // mesh in the scene the walk resp. the scan pass, which has to go through them anyway, is the cheaper way)
     if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && c->n_tri + c->n_msph <= 64) {
@@ -566,6 +573,19 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
             RRTX_HIP(launch_primary_lists<float>(P, pl, c->stream));
         }
         RRTX_HIP(hipStreamSynchronize(c->stream));
+        // the sky split: scenes of spheres alone (a LIST pass of any other scene tests every moving sphere and triangle too), no taper, a loop that runs at all
+        const uint32_t n_px = (uint32_t)((size_t)c->local_rows * c->p.image_width);
+        if (c->n_msph == 0 && c->n_tri == 0 && c->taper_pixel == n_px && c->p.max_depth > 0 && c->p.list_passes >= 0 && !(c->p.flags & (RRTX_FLAG_NO_SKY_SPLIT | RRTX_FLAG_VERIFY_LISTS))) {
+            const uint32_t blocks = (n_px + 255u) / 256u;
+            if (int e = ensure_buffer(c, (void **)&c->d_order, (size_t)n_px * sizeof(uint32_t))) return e;
+            if (int e = ensure_buffer(c, (void **)&c->d_order_scratch, ((size_t)blocks + 1) * sizeof(uint32_t))) return e;
+            RRTX_HIP(launch_order_pixels(pl, n_px, c->d_order_scratch, c->d_order, c->stream));
+            uint32_t n_first = 0;
+            RRTX_HIP(hipMemcpyAsync(&n_first, c->d_order_scratch + blocks, sizeof n_first, hipMemcpyDeviceToHost, c->stream));
+            RRTX_HIP(hipStreamSynchronize(c->stream));
+            if (n_first < n_px) // (a frame without a sky-only pixel keeps the plain queue)
+                c->n_queue_pixels = n_first, c->have_split = true;
+        }
     }
     // parked-item buffer: every resident wave can park at most kHandoffLanes items
     c->tail_capacity = 0;
@@ -628,7 +648,12 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
     auto enqueue = [&](auto fp) -> hipError_t {
         typedef decltype(fp) F;
         KernelParams<F> P = make_params<F>(c, out, c->accel);
-        hipError_t e = launch_render<F>(P, c->use_filter, c->lds_mode, c->grid_blocks, st);
+        hipError_t e = hipSuccess;
+        if (c->have_split) { // the tasks of the sky-only pixels: a dense kernel of camera rays (rrtx_kernels.hip: the sky split)
+            const uint32_t first = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel;
+            e = launch_sky_tasks<F>(P, first, c->total_tasks - first, c->num_cus, st);
+        }
+        if (e == hipSuccess) e = launch_render<F>(P, c->use_filter, c->lds_mode, c->grid_blocks, st);
         if (e == hipSuccess && c->tail_capacity)
             e = (c->accel || c->tail_grid) ? launch_resume<F>(make_params<F>(c, out, true), c->use_filter, c->resume_blocks, st) : launch_tail<F>(P, c->use_filter, c->tail_blocks, st);
         if (e == hipSuccess && c->use_partial) e = launch_finalize<F>((const F *)c->d_partial, (F *)d_rows, shape, st);

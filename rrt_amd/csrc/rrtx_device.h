@@ -197,6 +197,11 @@ template <typename F> struct KernelParams {
     int32_t n_always, n_grid_cells, n_grid_prims;
     GridRec<F> grid;
     const uint16_t *plist;   // camera-ray candidate lists [local pixel][kPlistStride], or nullptr
+    // The sky split (scenes of spheres alone with candidate lists): a pixel whose list is EMPTY is sky in every sample - its tasks are eight one-segment paths each, finished
+    // by sky_tasks_kernel, a dense kernel of nothing but camera rays, and never queued.  pixel_order is a stable partition of the local pixels, those with a non-empty list
+    // (or an overflowed one) first, n_queue_pixels of them: the render kernel's queue is positions [0, n_queue_pixels x chunks_per_pixel), the sky kernel takes the rest.
+    const uint32_t *pixel_order; // position -> local pixel, or nullptr: no split, the queue is every task as it lies
+    uint32_t n_queue_pixels;
     int32_t list_passes;     // 0 = every segment goes through the scan
     int32_t verify_lists;    // test mode: counters[2] counts camera rays whose list hit differs from the full scan
 };

@@ -578,8 +578,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 // guided batches: half of an even share of what is left of the region (chunk tasks, then
                 // single-sample tasks), so that the pools waves are left with shrink towards its end
                 uint32_t batch;
-                if (cursor_seen < P.taper_task_base) {
-                    batch = (P.taper_task_base - cursor_seen) / (2u * n_waves);
+                const uint32_t chunk_region_end = P.taper_task_base < P.total_tasks ? P.taper_task_base : P.total_tasks; // (the sky split: the queue ends before the last chunk task)
+                if (cursor_seen < chunk_region_end) {
+                    batch = (chunk_region_end - cursor_seen) / (2u * n_waves);
                     batch = batch < kTaskBatchMin ? kTaskBatchMin : (batch > kTaskBatch ? kTaskBatch : batch);
                 }
                 else {
@@ -610,7 +611,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     plist_count = 0xFFFFu; // a path in flight has no camera-ray list (a fresh camera ray fetches its own)
                 }
                 else {
-                    task = pool_next + rank;
+                    task = queue_task(*cold_params<F>(), pool_next + rank);
                     int pi, pj;
                     task_decode<F>(*cold_params<F>(), task, pi, pj, s_cur, s_end);
                     acc = mk<F>(0, 0, 0);
@@ -680,8 +681,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     const bool mine = pool_next + (uint32_t)lane < pool_end;
                     TailItem<F> fresh = {};
                     int pi, pj, sf = 0, se = 0;
-                    if (mine) task_decode<F>(*cold_params<F>(), pool_next + (uint32_t)lane, pi, pj, sf, se);
-                    fresh.task = pool_next + (uint32_t)lane, fresh.s_cur = sf, fresh.need_ray = 1u;
+                    const uint32_t fresh_task = mine ? queue_task(*cold_params<F>(), pool_next + (uint32_t)lane) : 0u;
+                    if (mine) task_decode<F>(*cold_params<F>(), fresh_task, pi, pj, sf, se);
+                    fresh.task = fresh_task, fresh.s_cur = sf, fresh.need_ray = 1u;
                     park(mine, fresh, se - sf < kTailSplit ? se - sf : kTailSplit);
                 }
                 break;
@@ -1744,6 +1746,102 @@ template <typename F> __global__ void __launch_bounds__(256) primary_lists_kerne
     out[0] = overflow ? (uint16_t)0xFFFFu : (uint16_t)count;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The sky split.  A pixel whose camera-ray candidate list is EMPTY cannot be hit by any camera ray of any of its samples (the lists are a proven superset,
+// primary_lists_kernel): every sample of it is ONE segment that ends in the sky (rrt.cu:69-75).  Inside the render loop such a sample still costs a trip through the
+// camera-ray section, a LIST pass and the shading of a miss - at a quarter of the lanes, between the scans and walks of the others.  Here the pixels of a scene are
+// partitioned once (order_*_kernel: stable, non-empty lists first), the render kernel's queue holds the first kind only, and sky_tasks_kernel finishes the tasks of the
+// second kind densely: one lane per task, nothing but camera rays (the generator and draws of the render kernel: camera_ray()) and the sky's colour, added up in sample
+// order into the task's slot (or, in per-sample launches, stored sample by sample) - the sums the render kernel would have formed, bit for bit.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) order_count_kernel(const uint16_t *plist, uint32_t n_pixels, uint32_t *block_counts)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool first = q < n_pixels && plist[(size_t)q * kPlistStride] != 0u; // (0xFFFF - an overflowed list - is of the first kind)
+    __shared__ uint32_t wave_n[4];
+    const uint64_t m = __ballot(first);
+    if ((threadIdx.x & 63u) == 0u) wave_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+__global__ void __launch_bounds__(1024) order_scan_kernel(uint32_t *block_counts, uint32_t n_blocks, uint32_t *total_first)
+{
+    // exclusive prefix sum of block_counts in place, by ONE block: each thread a contiguous run, the runs' sums scanned through LDS
+    __shared__ uint32_t run_sum[1024];
+    const uint32_t per = (n_blocks + 1023u) / 1024u, b0 = threadIdx.x * per < n_blocks ? threadIdx.x * per : n_blocks, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += block_counts[b];
+    run_sum[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const uint32_t v = run_sum[t];
+            run_sum[t] = acc;
+            acc += v;
+        }
+        *total_first = acc;
+    }
+    __syncthreads();
+    uint32_t acc = run_sum[threadIdx.x];
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t v = block_counts[b];
+        block_counts[b] = acc;
+        acc += v;
+    }
+}
+__global__ void __launch_bounds__(256) order_scatter_kernel(const uint16_t *plist, uint32_t n_pixels, const uint32_t *block_offsets, const uint32_t *total_first, uint32_t *order)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool in = q < n_pixels, first = in && plist[(size_t)q * kPlistStride] != 0u;
+    __shared__ uint32_t wave_n[4];
+    const uint64_t m = __ballot(first);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) wave_n[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0; // pixels of the first kind in this block's earlier waves ...
+    for (uint32_t w = 0; w < wave; ++w) before += wave_n[w];
+    const uint32_t first_before = block_offsets[blockIdx.x] + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); // ... and below this lane
+    if (!in) return;
+    // position of q: among its kind, in pixel order; the second kind starts where the first ends
+    order[first ? first_before : *total_first + (q - first_before)] = q;
+}
+template <typename F> __global__ void __launch_bounds__(256) sky_tasks_kernel(const KernelParams<F> P, uint32_t first_position, uint32_t n_positions)
+{
+    uint32_t n_samples = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_positions; i += gridDim.x * 256u) {
+        const uint32_t task = queue_task(P, first_position + i);
+        int pi, pj, s0, s1;
+        task_decode<F>(P, task, pi, pj, s0, s1);
+        V3<F> acc = mk<F>(0, 0, 0);
+        for (int s = s0; s < s1; ++s) {
+            Rng rng;
+            Path<F> path;
+            camera_ray<F>(P, pi, pj, s, rng, path);
+            const V3<F> radiance = vmul<F>(path.atten, sky_from_t<F>(sky_t<F>(vunit<F>(path.d)))); // shade(), the branch of a miss: rrt.cu:69-75
+            if (P.per_sample) {
+                F *o = P.out + ((size_t)task_pixel<F>(P, task) * (size_t)P.spp + (size_t)s) * 3;
+                o[0] = radiance.x, o[1] = radiance.y, o[2] = radiance.z;
+            }
+            else
+                acc = vadd<F>(acc, radiance); // rrt.cu:115
+        }
+        if (!P.per_sample) {
+            F *o = task_slot<F>(P, task);
+            o[0] = acc.x, o[1] = acc.y, o[2] = acc.z;
+        }
+        n_samples += (uint32_t)(s1 - s0);
+    }
+    if (P.collect_stats) { // one segment per sample; ONE atomic per block (a per-wave atomic on one word caps a dense kernel at 88 waves / us: EXPERIMENTS.md, round 4)
+        __shared__ uint32_t wave_n[4];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) n_samples += __shfl_xor(n_samples, off);
+        if ((threadIdx.x & 63u) == 0u) wave_n[threadIdx.x >> 6] = n_samples;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]);
+    }
+}
+
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
 // number of devices).  Launched unless every pixel is a single task.
 // kFinalizeGroup chunked pixels per block: their partial sums - [pixel][chunk][3], one contiguous slab - are staged through
@@ -1903,6 +2001,27 @@ template <typename F> hipError_t launch_primary_lists(const KernelParams<F> &P, 
     hipLaunchKernelGGL(primary_lists_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, plist);
     return hipGetLastError();
 }
+// pixel_order[n_pixels] from plist, the count of the first kind behind the block offsets; scratch: ceil(n_pixels / 256) + 1 dwords
+hipError_t launch_order_pixels(const uint16_t *plist, uint32_t n_pixels, uint32_t *scratch, uint32_t *order, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    const uint32_t blocks = (n_pixels + 255u) / 256u;
+    hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, stream, plist, n_pixels, scratch);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, scratch, blocks, scratch + blocks);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(blocks), dim3(256), 0, stream, plist, n_pixels, scratch, scratch + blocks, order);
+    return hipGetLastError();
+}
+template <typename F> hipError_t launch_sky_tasks(const KernelParams<F> &P, uint32_t first_position, uint32_t n_positions, int num_cus, hipStream_t stream)
+{
+    if (n_positions == 0) return hipSuccess;
+    uint32_t blocks = (n_positions + 255u) / 256u;
+    const uint32_t cap = (uint32_t)num_cus * 16u; // (grid-stride: a few thousand blocks, one statistics atomic each)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sky_tasks_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, first_position, n_positions);
+    return hipGetLastError();
+}
+template hipError_t launch_sky_tasks<float>(const KernelParams<float> &, uint32_t, uint32_t, int, hipStream_t);
+template hipError_t launch_sky_tasks<double>(const KernelParams<double> &, uint32_t, uint32_t, int, hipStream_t);
 #ifndef RRTX_TAIL_GROUP
 #define RRTX_TAIL_GROUP 8 // lanes per ray in the tail kernel (measured on final.txt spp 48: 32 -> 1.82, 16 -> 1.33, 8 -> 1.18, 4 -> 1.17 ms)
 #endif

@@ -284,6 +284,15 @@ template <typename F, typename PP> RRTX_DEV void task_decode(const PP &P, uint32
     px_j = (int)((tile * (uint32_t)P.shard_count + (uint32_t)P.shard_rank) * (uint32_t)P.tile_rows + (lr - tile * (uint32_t)P.tile_rows));
 }
 
+// Position in the work queue -> task (KernelParams::pixel_order: the sky split).  The chunks of a pixel stay together and in order; everything else - the slot a task's
+// sum goes to, the pixel and samples it stands for - is told by the TASK, so the order is scheduling only: the image does not know it.
+template <typename PP> RRTX_DEV uint32_t queue_task(const PP &P, uint32_t position)
+{
+    if (P.pixel_order == nullptr) return position;
+    const uint32_t slot = fdiv(position, P.div_cpp);
+    return P.pixel_order[slot] * (uint32_t)P.chunks_per_pixel + (position - slot * (uint32_t)P.chunks_per_pixel);
+}
+
 // Where a task's partial sum goes: task-major, [task][3] - chunked pixels first ([pixel < taper_pixel][chunk][3]: with one
 // chunk per pixel and no taper this IS the local frame), the single-sample tasks after them ([pixel - taper_pixel][sample][3]).
 // The lanes of a wave are handed consecutive tasks, so the 12-byte stores of a wave - minutes of kernel time apart, but
@@ -313,6 +322,11 @@ template <typename F, typename PP> RRTX_DEV void camera_ray(const PP &P, int px_
     path.depth = 0;
 }
 
+// The sky's colour for t = 0.5 (unit(d).y + 1): rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50).  One statement, shared by shade() and by the
+// kernel that finishes the sky-only pixels (sky_tasks_kernel): same operations, same bits.
+template <typename F> RRTX_DEV V3<F> sky_from_t(F t) { return vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0))); }
+template <typename F> RRTX_DEV F sky_t(const V3<F> &unit_dir) { return (F)0.5 * (unit_dir.y + (F)1.0); }
+
 // One bounce given the closest hit (rrt.cu:49-76).  Returns true when the path ended, with its
 // radiance; otherwise `path` is the scattered ray.
 // SO ("spheres only"): the scene holds neither moving spheres nor triangles - the branches that tell the kinds apart are
@@ -327,10 +341,8 @@ template <typename F, bool SO = false> RRTX_DEV bool shade(const KernelParams<F>
     // and the division three times
     const V3<F> ud = vunit<F>(path.d);
     if (best.idx < 0) {
-        // sky, rrt.cu:69-75 with the CPU build's scalar types (rrt.cpp:47-50)
-        const F t = (F)0.5 * (ud.y + (F)1.0);
-        const V3<F> c = vadd<F>(vscale<F>((F)1.0 - t, mk<F>((F)1.0, (F)1.0, (F)1.0)), vscale<F>(t, mk<F>((F)0.5, (F)0.7, (F)1.0)));
-        radiance = vmul<F>(path.atten, c);
+        // sky, rrt.cu:69-75
+        radiance = vmul<F>(path.atten, sky_from_t<F>(sky_t<F>(ud)));
         return true;
     }
     // hit record: sphere.h:51-55 / moving_sphere.h:50-55 / triangle.h:64-67
