@@ -205,6 +205,8 @@ FLAG_NO_TAIL_GRID = 128
 FLAG_SCAN_NO_MFMA = 256
 FLAG_ONE_ITEM_PER_PIXEL = 512
 FLAG_NO_SKY_SPLIT = 1024
+FLAG_NO_FIRST_BOUNCE = 2048
+FLAG_FIRST_BOUNCE_ALWAYS = 4096
 
 
 class RrtxError(RuntimeError):

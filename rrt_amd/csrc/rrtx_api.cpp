@@ -42,6 +42,7 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int kEventRing = 64;
+constexpr size_t kFirstBounceMinSamples = (size_t)32 << 20; // see set_scene
 
 } // namespace
 
@@ -83,6 +84,8 @@ struct rrtx_ctx {
     uint32_t *d_order = nullptr, *d_order_scratch = nullptr; // the sky split (KernelParams::pixel_order): the pixels with a non-empty list first ...
     uint32_t n_queue_pixels = 0;  // ... this many of them
     bool have_split = false;
+    void *d_first = nullptr;      // the first-bounce records of a launch (KernelParams::first)
+    bool have_first = false;
     // accelerated closest hit (use_bvh): uniform grid + always-list, see build_grid()
     bool accel = false;
     bool tail_grid = false;   // list scan (-b), but what a launch parks at its end is finished through the grid (a RESUME pass: same bits)
@@ -277,6 +280,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
         memcpy(&P.grid, c->grid_bytes, sizeof(GridRec<F>));
     }
     P.plist = c->have_plist ? c->d_plist : nullptr;
+    P.first = c->have_first ? c->d_first : nullptr;
     if (c->have_split) {
         P.pixel_order = c->d_order, P.n_queue_pixels = c->n_queue_pixels;
         P.total_tasks = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel; // the render kernel's queue; sky_tasks_kernel takes the positions behind it
@@ -294,13 +298,13 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
 void free_scene_buffers(rrtx_ctx *c)
 {
     void **bufs[] = {&c->d_hot, &c->d_filter, &c->d_cold, &c->d_msph, &c->d_tri, &c->d_tri_scan, &c->d_mat, (void **)&c->d_grid_cell_start, (void **)&c->d_grid_cell_prims,
-                     (void **)&c->d_grid_always, (void **)&c->d_mf_table, (void **)&c->d_mf_big, (void **)&c->d_plist, (void **)&c->d_order, (void **)&c->d_order_scratch, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
+                     (void **)&c->d_grid_always, (void **)&c->d_mf_table, (void **)&c->d_mf_big, (void **)&c->d_plist, (void **)&c->d_order, (void **)&c->d_order_scratch, &c->d_first, &c->d_tail_items, &c->d_tail_rad, (void **)&c->d_tail_units};
     for (void **b : bufs) {
         if (*b) (void)hipFree(*b);
         *b = nullptr;
     }
     c->caps.clear();
-    c->have_scene = c->have_plist = c->have_split = false;
+    c->have_scene = c->have_plist = c->have_split = c->have_first = false;
     c->accel = c->tail_grid = false;
     c->tail_capacity = 0;
 }
@@ -556,7 +560,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
     if (grid < 1) grid = 1;
     c->grid_blocks = (int)grid;
     // camera-ray candidate lists (one pre-pass per scene: they depend on the camera and the spheres)
-    c->have_plist = c->have_split = false;
+    c->have_plist = c->have_split = c->have_first = false;
     // (a LIST pass tests every moving sphere and triangle per camera ray, with the few lanes that hold one: with a
     // mesh in the scene the walk resp. the scan pass, which has to go through them anyway, is the cheaper way)
     if (!(c->p.flags & RRTX_FLAG_NO_PRIMARY_LISTS) && c->n_sph <= 65535 && c->local_rows > 0 && c->n_tri + c->n_msph <= 64) {
@@ -585,6 +589,35 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
             RRTX_HIP(hipStreamSynchronize(c->stream));
             if (n_first < n_px) // (a frame without a sky-only pixel keeps the plain queue)
                 c->n_queue_pixels = n_first, c->have_split = true;
+        }
+        // the first bounce of every queued sample as a dense pre-pass of each launch: 8 F per sample (15 GB for 1200x800 spp 500 in fp32) - where the device can
+        // spare that and where it pays.  Measured on one box (EXPERIMENTS.md, round 4): with the grid walk 37.3 -> 36.3 ms (fp32) and 60.3 -> 56.4 ms (fp64) at
+        // 1200x800 spp 500, nothing at a shard of 8 of it (60 M samples), 1.16 -> 1.41 ms at spp 10; with the list scan nothing anywhere (its loop is bound by
+        // the scan passes, which a lane without a camera ray does not shorten).  Otherwise, and for scenes with anything but spheres, the render loop forms its
+        // camera rays itself (LIST passes), as up to round 3.
+        const bool first_pays = (c->p.flags & RRTX_FLAG_FIRST_BOUNCE_ALWAYS) || (c->accel && (size_t)c->total_tasks * (size_t)c->chunk >= kFirstBounceMinSamples);
+        if (first_pays && c->n_msph == 0 && c->n_tri == 0 && c->taper_pixel == n_px && c->p.max_depth > 0 && c->p.list_passes >= 0 && c->n_mat <= 65536 &&
+            !(c->p.flags & (RRTX_FLAG_NO_FIRST_BOUNCE | RRTX_FLAG_VERIFY_LISTS))) {
+            const size_t bytes = (((size_t)c->total_tasks + 63) / 64) * 64 * (size_t)c->chunk * 8 * c->fsize;
+            size_t free_b = 0, total_b = 0;
+            if (bytes <= ((size_t)96 << 30) && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                size_t *cap = nullptr;
+                for (auto &e : c->caps)
+                    if (e.first == &c->d_first) cap = &e.second;
+                if (!cap) {
+                    c->caps.push_back({&c->d_first, 0});
+                    cap = &c->caps.back().second;
+                }
+                if (!c->d_first || *cap < bytes) { // (exactly what is wanted: no room to grow on a buffer this size)
+                    if (c->d_first) (void)hipFree(c->d_first);
+                    c->d_first = nullptr, *cap = 0;
+                    if (bytes + ((size_t)4 << 30) <= free_b + 0 && hipMalloc(&c->d_first, bytes + 64) == hipSuccess)
+                        *cap = bytes;
+                    else
+                        c->d_first = nullptr, (void)hipGetLastError();
+                }
+                c->have_first = c->d_first != nullptr;
+            }
         }
     }
     // parked-item buffer: every resident wave can park at most kHandoffLanes items
@@ -653,6 +686,7 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
             const uint32_t first = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel;
             e = launch_sky_tasks<F>(P, first, c->total_tasks - first, c->num_cus, st);
         }
+        if (e == hipSuccess && c->have_first) e = launch_first_bounce<F>(P, P.total_tasks, c->num_cus, st); // (the queue's positions: every task, or those of the pixels the sky split left)
         if (e == hipSuccess) e = launch_render<F>(P, c->use_filter, c->lds_mode, c->grid_blocks, st);
         if (e == hipSuccess && c->tail_capacity)
             e = (c->accel || c->tail_grid) ? launch_resume<F>(make_params<F>(c, out, true), c->use_filter, c->resume_blocks, st) : launch_tail<F>(P, c->use_filter, c->tail_blocks, st);

@@ -40,6 +40,29 @@ constexpr int kWavesPerBlock = kBlockThreads / 64;
 #define RRTX_MF_BLOCK_THREADS_F64 768 // (fp64 ray records and result slots: 6.75 KB a wave - ONE block of twelve waves to a CU, three to a SIMD: 66.5 ms; 256 threads, two blocks = 2 waves per SIMD: 79.2; 384, six waves spread unevenly over the four SIMDs: 104.8)
 #endif
 constexpr int mf_block_threads(size_t fsize) { return fsize == 4 ? RRTX_MF_BLOCK_THREADS : RRTX_MF_BLOCK_THREADS_F64; }
+// A first-bounce record: part 0 = {o.x, o.y, o.z, d.x}, part 1 = {d.y, d.z, code, -}; code (an integer of F's size, its low 32 bits used): kind << 30 | draws << 16 | material.
+//   kFirstRay     : the path goes on from o along d at depth 1; its attenuation is the material's albedo (1 for a dielectric), its generator stands at draw `draws`
+//   kFirstDone    : the path ended at its first segment - sky, absorbed, or a depth limit of 1 -, o is its radiance
+//   kFirstUnknown : not resolved here (a pixel whose candidate list overflowed; more than 16 383 draws): the render kernel traces the sample from its camera ray
+// Layout: part p of sample k of a task at [((task / 64) x chunk + k) x 2 + p][task % 64], 4 F each - the dense kernel runs one lane per task, so the 64 lanes of a wave
+// write a part side by side (1 KB per store instruction in fp32), and the render kernel's lanes, which hold neighbouring tasks, read them the same way.
+constexpr uint32_t kFirstRay = 0u, kFirstDone = 1u, kFirstUnknown = 3u;
+template <typename F> struct FirstCode;
+template <> struct FirstCode<float> {
+    typedef uint32_t type;
+};
+template <> struct FirstCode<double> {
+    typedef uint64_t type;
+};
+inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    size_t first_slot(uint32_t task, uint32_t k, uint32_t chunk, uint32_t part)
+{
+    return (((size_t)(task >> 6) * chunk + k) * 2u + part) * 64u + (task & 63u);
+}
+
 constexpr uint32_t kTaskBatch = 64;    // chunk tasks a wave pulls from the global queue at a time, at most ...
 constexpr uint32_t kTaskBatchMin = 8; // ... and at least (guided: batches shrink towards the end of the chunk tasks)
 constexpr uint32_t kQueueOverFlag = 32; // P.queue[32] (its own 128-byte line): set once the cursor has passed the last task
@@ -202,6 +225,10 @@ template <typename F> struct KernelParams {
     // (or an overflowed one) first, n_queue_pixels of them: the render kernel's queue is positions [0, n_queue_pixels x chunks_per_pixel), the sky kernel takes the rest.
     const uint32_t *pixel_order; // position -> local pixel, or nullptr: no split, the queue is every task as it lies
     uint32_t n_queue_pixels;
+    // The first bounce, done densely before the render kernel starts (first_bounce_kernel; scenes of spheres alone with candidate lists): per sample of every queued
+    // task ONE record of 8 F - see FirstCode, first_slot - that says how the sample's camera ray fared: the path ended (its radiance), or it goes on (the scattered
+    // ray, the material whose albedo is its attenuation, the draws consumed).  The render kernel then forms no camera ray, runs no LIST pass and shades no primary hit.
+    const void *first;           // [first_slot(task, sample of its chunk, part)] of 4 F each, or nullptr
     int32_t list_passes;     // 0 = every segment goes through the scan
     int32_t verify_lists;    // test mode: counters[2] counts camera rays whose list hit differs from the full scan
 };

@@ -693,13 +693,51 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         RRTX_SEC(1); // camera rays
         if (alive && need_ray) {
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
-            need_ray = false;
             int pi, pj, sf, se;
             const auto &C = *cold_params<F>();
             task_decode<F>(C, task, pi, pj, sf, se);
-            camera_ray<F>(C, pi, pj, s_cur, rng, path);
-            // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
-            plist_count = C.plist ? (uint32_t)C.plist[(size_t)task_pixel<F>(C, task) * kPlistStride] : 0xFFFFu;
+            if (C.first == nullptr) {
+                need_ray = false;
+                camera_ray<F>(C, pi, pj, s_cur, rng, path);
+                // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
+                plist_count = C.plist ? (uint32_t)C.plist[(size_t)task_pixel<F>(C, task) * kPlistStride] : 0xFFFFu;
+            }
+            else {
+                // The first bounce of every sample was done before this kernel started (first_bounce_kernel: one lane per task, all lanes at work on neighbouring
+                // samples of a pixel - camera ray, the pixel's candidate list, the primary hit's shading).  Here a fresh sample is a record: the path ended - its
+                // radiance is added, on to the next sample -, or it goes on: the lane takes the scattered ray up at depth 1.  No camera ray is formed in this loop, no
+                // LIST pass runs, no primary hit is shaded: what used to be 28 - 32 % of the kernel's cycles at a quarter of the lanes (EXPERIMENTS.md, round 4).
+                typedef F FV4 __attribute__((ext_vector_type(4)));
+                typedef typename FirstCode<F>::type Code;
+                const FV4 *const recs = (const FV4 *)C.first;
+                plist_count = 0xFFFFu;
+                while (need_ray) {
+                    const uint32_t k = (uint32_t)(s_cur - sf);
+                    const FV4 p0 = recs[first_slot(task, k, (uint32_t)C.chunk, 0u)], p1 = recs[first_slot(task, k, (uint32_t)C.chunk, 1u)];
+                    // (the code word through an integer load of its own: the compiler took element 0 for `bit_cast(p1.z)` of the vector load - ISA checked)
+                    const uint32_t code = (uint32_t)((const Code *)(recs + first_slot(task, k, (uint32_t)C.chunk, 1u)))[2];
+                    const uint32_t kind = code >> 30;
+                    if (kind == kFirstDone) {
+                        need_ray = false;
+                        n_segments += 1; // (counted where the record is consumed: a sample the tail kernel finishes is traced there from its camera ray, and counted there)
+                        finish_sample<F, RESUME>(P, mk<F>(p0.x, p0.y, p0.z), task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
+                        continue;
+                    }
+                    need_ray = false;
+                    if (kind == kFirstUnknown) { // traced from its camera ray, like any ray (its pixel has no usable list)
+                        camera_ray<F>(C, pi, pj, s_cur, rng, path);
+                        break;
+                    }
+                    n_segments += 1;
+                    const MaterialRec<F> m = P.mat[code & 0xFFFFu];
+                    path.o = mk<F>(p0.x, p0.y, p0.z), path.d = mk<F>(p0.w, p1.x, p1.y);
+                    path.tm = 0; // (scenes of spheres alone: nothing moves)
+                    path.atten = m.type == 2 ? mk<F>((F)1.0, (F)1.0, (F)1.0) : mk<F>(m.r, m.g, m.b); // rrt.cu:58 at depth 0: (1, 1, 1) x albedo
+                    path.depth = 1;
+                    rng_open(rng, C.seed, (uint32_t)(pj * C.W + pi), (uint32_t)s_cur);
+                    rng.n = (code >> 16) & 0x3FFFu;
+                }
+            }
         }
 
         // ---------------- pass mode --------------------------------------------------------------------
@@ -712,7 +750,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // (kDensePairs: which accelerated variants share the (ray, entry) pairs of a wave out over its lanes - see the other branch)
         if constexpr (!kDensePairs) {
         RRTX_SEC(2); // camera-ray lists (LIST passes) / walk
-        const bool has_list = alive && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0 && !(ACCEL != 0 && in_walk);
+        // (a lane whose task ended among its first-bounce records has nothing to intersect: it waits for the next hand-out)
+        const bool has_list = alive && !need_task && path.depth == 0 && plist_count != 0xFFFFu && P.max_depth > 0 && !(ACCEL != 0 && in_walk);
         const bool list_pass = list_passes_done < P.list_passes && __ballot(has_list) != 0ull;
         list_passes_done = list_pass ? list_passes_done + 1 : 0;
 
@@ -727,7 +766,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
         // exact test with the ray's record from LDS, and hits go to the ray's owner through an LDS minimum over (t, index) - consider()'s
         // order-free rule, as in dense_candidates().  `best` is then what the scan section further down would have found.
         if constexpr (LDSMODE == 3) {
-        const bool scans = alive && P.max_depth > 0 && !list_pass;
+        const bool scans = alive && !need_task && P.max_depth > 0 && !list_pass;
         if (__ballot(scans) != 0ull) {
             RRTX_SEC(3);
             typedef _Float16 H8 __attribute__((ext_vector_type(8)));
@@ -969,7 +1008,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             RRTX_SEC(2);
         }
         }
-        if (alive && (!list_pass || has_list)) {
+        if (alive && !need_task && (!list_pass || has_list)) {
             bool done = false;
             V3<F> radiance = mk<F>(0, 0, 0);
             if (P.max_depth <= 0) { // rrt.cu:47 loop body never runs
@@ -1221,9 +1260,10 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             WalkRanges R = {0u, 0u, 0u, 0u, 0u, 0u};
             bool is_list = false, walking = false, ended = false;
             F t_last = 0, slack_t = 0, a = 0;
-            if (alive && P.max_depth <= 0) // rrt.cu:47 loop body never runs
+            const bool has_ray = alive && !need_task; // (a lane whose task ended among its first-bounce records waits for the next hand-out)
+            if (has_ray && P.max_depth <= 0) // rrt.cu:47 loop body never runs
                 done = true;
-            else if (alive) {
+            else if (has_ray) {
                 a = vlen2<F>(path.d); // sphere.h:36
                 if (!in_walk) {
                     n_segments += 1;
@@ -1842,6 +1882,64 @@ template <typename F> __global__ void __launch_bounds__(256) sky_tasks_kernel(co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The first bounce, densely (KernelParams::first; scenes of spheres alone with candidate lists).  One lane per queued task; for each sample of the task the camera ray
+// (camera_ray(): the generator and draws of the render loop), the reference's scan over the only spheres a camera ray of that pixel can meet - the pixel's candidate
+// list in index order with the running closest hit: hittable_list.h:95-117 restricted to a proven superset, what a LIST pass of the render loop did -, and the bounce
+// (shade(): rrt.cu:49-76).  What is left of the sample is ONE record (rrtx_device.h): the path ended, with its radiance, or it goes on - origin, direction, the material
+// whose albedo is the attenuation, the position of the generator.  Neighbouring lanes hold neighbouring chunks of one pixel and walk the same list: all 64 lanes work,
+// where the render loop served camera rays with a quarter of them between the scans and walks of the rest (round 4 measured the dense form of a camera ray at a third
+// of its cost inside the loop: the sky split).  32 bytes per sample written, read once by the lane that owns the task: 15 GB for 1200x800 spp 500.
+// ---------------------------------------------------------------------------------------------
+template <typename F> __global__ void __launch_bounds__(256) first_bounce_kernel(const KernelParams<F> P, uint32_t n_positions)
+{
+    typedef F FV4 __attribute__((ext_vector_type(4)));
+    typedef typename FirstCode<F>::type Code;
+    __shared__ uint32_t list_lds[8][256]; // a thread's copy of its pixel's list (8 dwords), word k at [k][thread]: no bank conflicts, nobody else's business
+    FV4 *const recs = (FV4 *)P.first;
+    const F t_min = (F)0.001; // rrt.cpp:32
+    uint32_t *const mine = &list_lds[0][threadIdx.x];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_positions; i += gridDim.x * 256u) {
+        const uint32_t task = queue_task(P, i);
+        int pi, pj, s0, s1;
+        task_decode<F>(P, task, pi, pj, s0, s1);
+        typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+        const U4 *pl4 = (const U4 *)(P.plist + (size_t)task_pixel<F>(P, task) * kPlistStride);
+        const U4 lo4 = pl4[0], hi4 = pl4[1];
+        mine[0 * 256] = lo4.x, mine[1 * 256] = lo4.y, mine[2 * 256] = lo4.z, mine[3 * 256] = lo4.w;
+        mine[4 * 256] = hi4.x, mine[5 * 256] = hi4.y, mine[6 * 256] = hi4.z, mine[7 * 256] = hi4.w;
+        const uint32_t count = lo4.x & 0xFFFFu; // halfword 0: the count, or 0xFFFF = "scan everything"
+        for (int s = s0; s < s1; ++s) {
+            FV4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+            uint32_t code = kFirstUnknown << 30;
+            if (count != 0xFFFFu) {
+                Rng rng;
+                Path<F> path;
+                camera_ray<F>(P, pi, pj, s, rng, path);
+                const F a = vlen2<F>(path.d); // sphere.h:36
+                HitInfo<F> best = {Limits<F>::inf(), -1};
+                for (uint32_t k = 1; k <= count; ++k) {
+                    const int idx = (int)((mine[(k >> 1) * 256] >> ((k & 1u) * 16u)) & 0xFFFFu);
+                    const SphereHot<F> g = P.sph_hot[idx];
+                    refine_sphere<F>(g.cx, g.cy, g.cz, g.r2, path, a, t_min, idx, best);
+                }
+                V3<F> radiance;
+                const bool done = shade<F, true>(P, best, path, rng, radiance); // rrt.cu:49-76, the bounce at depth 0
+                if (done)
+                    p0.x = radiance.x, p0.y = radiance.y, p0.z = radiance.z, code = kFirstDone << 30;
+                else if (rng.n <= 0x3FFFu) {
+                    p0.x = path.o.x, p0.y = path.o.y, p0.z = path.o.z, p0.w = path.d.x, p1.x = path.d.y, p1.y = path.d.z;
+                    code = (kFirstRay << 30) | (rng.n << 16) | (uint32_t)P.sph_cold[best.idx].mat;
+                }
+            }
+            p1.z = __builtin_bit_cast(F, (Code)code);
+            const uint32_t k = (uint32_t)(s - s0);
+            recs[first_slot(task, k, (uint32_t)P.chunk, 0u)] = p0;
+            recs[first_slot(task, k, (uint32_t)P.chunk, 1u)] = p1;
+        }
+    }
+}
+
 // Sums the per-task partials of each pixel in chunk order (fixed shape => same image for any
 // number of devices).  Launched unless every pixel is a single task.
 // kFinalizeGroup chunked pixels per block: their partial sums - [pixel][chunk][3], one contiguous slab - are staged through
@@ -2020,6 +2118,17 @@ template <typename F> hipError_t launch_sky_tasks(const KernelParams<F> &P, uint
     hipLaunchKernelGGL(sky_tasks_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, first_position, n_positions);
     return hipGetLastError();
 }
+template <typename F> hipError_t launch_first_bounce(const KernelParams<F> &P, uint32_t n_positions, int num_cus, hipStream_t stream)
+{
+    if (n_positions == 0) return hipSuccess;
+    uint32_t blocks = (n_positions + 255u) / 256u;
+    const uint32_t cap = (uint32_t)num_cus * 16u; // (grid-stride: a few thousand blocks, one statistics atomic each)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(first_bounce_kernel<F>, dim3(blocks), dim3(256), 0, stream, P, n_positions);
+    return hipGetLastError();
+}
+template hipError_t launch_first_bounce<float>(const KernelParams<float> &, uint32_t, int, hipStream_t);
+template hipError_t launch_first_bounce<double>(const KernelParams<double> &, uint32_t, int, hipStream_t);
 template hipError_t launch_sky_tasks<float>(const KernelParams<float> &, uint32_t, uint32_t, int, hipStream_t);
 template hipError_t launch_sky_tasks<double>(const KernelParams<double> &, uint32_t, uint32_t, int, hipStream_t);
 #ifndef RRTX_TAIL_GROUP

@@ -98,3 +98,36 @@ def test_reference_summation_order_at_the_speed_of_small_work_items(gpu, fp64):
         r = gpu.Rrt(mw, mh, ms, 50, fp64=True, sample_chunk=-1, use_bvh=True)
         assert np.array_equal(r.render(gpu.Scene(mesh, mw, mh, fp64=True)), want_m)
         r.close()
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_sky_split_and_first_bounce_leave_the_frame_alone(gpu, fp64):
+    """Round 4's two dense pre-passes of a launch, for scenes of spheres alone: the pixels with an empty camera-ray candidate list are finished by a kernel of
+    their own (the sky split; off: RRTX_FLAG_NO_SKY_SPLIT), and the first bounce of every queued sample is left as a record (used by itself only for large
+    use_bvh launches; forced here: RRTX_FLAG_FIRST_BOUNCE_ALWAYS).  Every combination, both closest-hit modes, chunked and reference-order summation, a
+    hand-off that parks most of the launch, a depth limit of 1 (every record ends its path) and of 0 (no loop at all) - against the oracle, segments included."""
+    f, w, h, spp = scene_path("final"), 120, 80, 24
+    sc = gpu.Scene(f, w, h, fp64=fp64)
+    orc = Oracle(f, w, h, fp64)
+    want = {(d, ch): orc.render(spp, d, 1984, order=1, **({"chunk": ch} if ch else {})) for d in (50, 1, 0) for ch in (8, None)}
+    combos = [0, gpu.FLAG_NO_SKY_SPLIT, gpu.FLAG_FIRST_BOUNCE_ALWAYS, gpu.FLAG_FIRST_BOUNCE_ALWAYS | gpu.FLAG_NO_SKY_SPLIT, gpu.FLAG_NO_FIRST_BOUNCE]
+    for flags in combos:
+        for kw in (dict(use_bvh=False), dict(use_bvh=True), dict(use_bvh=True, handoff_lanes=64, handoff_iters=1), dict(use_bvh=False, sample_chunk=-1),
+                   dict(use_bvh=True, max_depth=1), dict(use_bvh=False, max_depth=0)):
+            kw = dict(kw)
+            depth = kw.pop("max_depth", 50)
+            r = gpu.Rrt(w, h, spp, depth, fp64=fp64, flags=flags, **kw)
+            fb = r.render(sc)
+            fb2 = r.render()  # (the record buffer and the queue are per launch: a second launch of the same context)
+            st = dict(r.stats)
+            r.close()
+            img, so = want[(depth, None if kw.get("sample_chunk") == -1 else 8)]
+            assert np.array_equal(fb, img) and np.array_equal(fb2, img), (flags, kw, depth)
+            assert st["segments"] == so["segments"] and st["convergence_faults"] == 0, (flags, kw, depth)
+    # a shard of the frame, and a frame whose every pixel has candidates (no sky-only pixel: the plain queue)
+    for flags in (0, gpu.FLAG_FIRST_BOUNCE_ALWAYS):
+        r = gpu.Rrt(w, h, spp, 50, fp64=fp64, use_bvh=True, flags=flags, shard_rank=1, shard_count=3, tile_rows=4)
+        fb = r.render(sc)
+        rows = r.shard_rows()
+        r.close()
+        assert np.array_equal(fb[rows], want[(50, 8)][0][rows])
