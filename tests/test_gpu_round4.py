@@ -131,3 +131,47 @@ def test_sky_split_and_first_bounce_leave_the_frame_alone(gpu, fp64):
         rows = r.shard_rows()
         r.close()
         assert np.array_equal(fb[rows], want[(50, 8)][0][rows])
+
+
+R4_CASES = int(os.environ.get("RRTX_R4_CASES", "8"))
+
+
+@pytest.mark.parametrize("fp64", [False, True], ids=["f32", "f64"])
+def test_random_scenes_of_spheres_through_the_dense_passes(gpu, tmp_path, fp64):
+    """A campaign over random scenes of spheres alone (the scenes the sky split and the first-bounce pre-pass exist for), random frames, depth limits, summation
+    orders, hand-offs and shards, the two passes on, off and forced, both closest-hit modes: frames and segment counts equal to the oracle's in every bit.
+    RRTX_R4_CASES scales it (round 4 ran 3 000 per precision on the final kernels: no pixel off)."""
+    from _oracle import crowded_scene
+
+    rng = np.random.default_rng(404 + (1 if fp64 else 0))
+    flag_sets = [0, gpu.FLAG_FIRST_BOUNCE_ALWAYS, gpu.FLAG_FIRST_BOUNCE_ALWAYS | gpu.FLAG_NO_SKY_SPLIT, gpu.FLAG_NO_SKY_SPLIT, gpu.FLAG_FIRST_BOUNCE_ALWAYS | gpu.FLAG_NO_TAIL_GRID]
+    bad = []
+    for case in range(R4_CASES):
+        f = str(tmp_path / ("r4_%d.txt" % case))
+        crowded_scene(rng, f, spheres_only=True)
+        w, h = int(rng.integers(16, 129)), int(rng.integers(16, 81))
+        spp = int(rng.choice([1, 3, 8, 9, 16, 24, 40]))
+        depth = int(rng.choice([50, 50, 7, 2, 1]))
+        reference_order = bool(rng.integers(0, 4) == 0)
+        shards = int(rng.choice([1, 1, 2, 3]))
+        kw = dict(tile_rows=int(rng.choice([1, 4, 16])), handoff_lanes=int(rng.choice([0, 0, 12, 64])), handoff_iters=int(rng.choice([0, 1, 12])), flags=int(rng.choice(flag_sets)))
+        if reference_order:
+            kw["sample_chunk"] = -1
+        want, so = Oracle(f, w, h, fp64).render(spp, depth, 1984, order=1, **({} if reference_order else {"chunk": 8}))
+        sc = gpu.Scene(f, w, h, fp64=fp64)
+        for use_bvh in (False, True):
+            got = np.zeros_like(want)
+            segments = 0
+            for rank in range(shards):
+                r = gpu.Rrt(w, h, spp, depth, use_bvh=use_bvh, fp64=fp64, shard_rank=rank, shard_count=shards, **kw)
+                part = r.render(sc)
+                rows = r.shard_rows()
+                got[rows] = part[rows]
+                st = dict(r.stats)
+                segments += st["segments"]
+                r.close()
+            if not (np.array_equal(got, want) and segments == so["segments"]):
+                bad.append((case, "use_bvh" if use_bvh else "list scan", w, h, spp, depth, shards, kw, float((got != want).any(axis=2).mean()), segments, so["segments"]))
+        if case % 50 == 49:
+            print("round-4 campaign %s: %d cases, %d bad" % ("f64" if fp64 else "f32", case + 1, len(bad)), flush=True)
+    assert not bad, bad
