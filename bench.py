@@ -398,6 +398,7 @@ def main():
         elapsed_a, sta = timed(sa, args.steps, 1)
         accel = {"value": round(W * H * spp / (elapsed_a / args.steps) / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(elapsed_a / args.steps * 1e3, 3),
                  "kernel_ms": round(sta["kernel_ms_sum"] / max(1, sta["renders"]), 3), "grid_cells": sta["accel_cells"],
+                 "sky_pixels": int(sta.get("sky_pixels", 0)), "first_bounce_prepass": int(sta.get("first_bounce", 0)),
                  "note": "use_bvh = 1 (the CLI's default, as the reference's BVH is): closest hit through a uniform grid + always-list, exact test and tie rules of the list scan, "
                          "image bit-identical for spheres, moving spheres and fp64 meshes - this scene: yes (tests/test_gpu_configs.py; fp32 triangle meshes are gridded under a stated "
                          "tolerance, rrtx_stats.accel_exact = 0, `rrt -X` / -b for the list scan's bits); segments fall back to the list scan only for rays outside the grid's proven range (DESIGN.md 3b)"}
@@ -623,7 +624,8 @@ def main():
             "config": {"workload": "%s: scenes/final.txt %dx%d spp=%d d=%d fp32, list scan of 488 spheres (-b; camera rays via per-pixel candidate lists, every other segment through the whole list)" % (wl_name, W, H, spp, DEPTH),
                        "parallelism": "row-tile shards x%d (tile_rows=%d)%s" % (world, args.tile_rows, ", one RCCL gather to rank 0 per step" if world > 1 else ""),
                        "sample_chunk": st["sample_chunk"], "segments_per_sample": round(segments / samples, 4), "prim_tests_per_launch": int(prim_tests),
-                       "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4)},
+                       "prim_tests_executed_per_launch": int(scanned * 488 + candidates), "scanned_segments_per_sample": round(scanned / samples, 4),
+                       "sky_pixels": int(st.get("sky_pixels", 0)), "first_bounce_prepass": int(st.get("first_bounce", 0))},
             "roofline": roof,
         }
         if kernel_only is not None:

@@ -30,7 +30,7 @@ extern "C" {
  * a host compiled against a header of another RRTX_ABI_VERSION must not pass its own structs.  Check once at start-up:
  *     if (rrtx_abi_version() != RRTX_ABI_VERSION) refuse;
  * History: 3 = round 3 (rrtx_stats grew walk_cells / walk_pairs, rrtx_group_stats the RCCL fields, without a bump: that
- * was a silent break); 4 = rrtx_stats.convergence_faults. */
+ * was a silent break); 4 = rrtx_stats.convergence_faults, sky_pixels, first_bounce. */
 #define RRTX_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------- */
@@ -220,6 +220,10 @@ typedef struct rrtx_stats {
                                 triangles / moving spheres under use_bvh) only, 0 elsewhere                                */
     uint64_t convergence_faults; /* waves that reached a wave-wide step (matrix-core scan, dense pairing) with lanes masked off: must
                                 be 0 - the kernels count it instead of assuming it (always collected)                      */
+    int32_t sky_pixels;      /* pixels of this shard whose work items a dense kernel of camera rays finished (their candidate list is empty: sky in
+                                every sample); 0 = no split (RRTX_FLAG_NO_SKY_SPLIT, scenes with anything but spheres, no such pixel)     */
+    int32_t first_bounce;    /* 1: the first bounce of every queued sample was a dense pre-pass of the launch (RRTX_FLAG_NO_FIRST_BOUNCE /
+                                RRTX_FLAG_FIRST_BOUNCE_ALWAYS; by itself: use_bvh, spheres alone, 32 M samples and more, memory to spare)  */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

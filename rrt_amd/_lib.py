@@ -79,6 +79,8 @@ class Stats(C.Structure):  # rrtx_stats
         ("walk_cells", C.c_uint64),
         ("walk_pairs", C.c_uint64),
         ("convergence_faults", C.c_uint64),
+        ("sky_pixels", C.c_int32),
+        ("first_bounce", C.c_int32),
     ]
 
     def as_dict(self):

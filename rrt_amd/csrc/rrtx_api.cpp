@@ -756,6 +756,8 @@ int rrtx_collect(rrtx_ctx *c, rrtx_stats *stats)
         stats->renders = (int32_t)(c->renders_total - before_n);
         stats->wall_ms = c->last_wall_ms;
         stats->samples = (uint64_t)c->local_rows * c->p.image_width * (uint64_t)c->p.samples_per_pixel;
+        stats->sky_pixels = c->have_split ? (int32_t)((size_t)c->local_rows * c->p.image_width - c->n_queue_pixels) : 0;
+        stats->first_bounce = c->have_first ? 1 : 0;
         {
             unsigned long long faults = 0;
             RRTX_HIP(hipMemcpy(&faults, c->d_counters + 6, sizeof faults, hipMemcpyDeviceToHost));
