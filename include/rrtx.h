@@ -182,6 +182,9 @@ typedef struct rrtx_params {
 /* Keep the pixels whose camera-ray candidate list is empty - sky in every sample - in the render kernel's queue instead of finishing their work items in a dense
  * kernel of their own (A/B switch; the images are identical). */
 #define RRTX_FLAG_NO_SKY_SPLIT 1024
+/* Launch that kernel on the render's own stream, ahead of the render kernel, as round 4 first had it, instead of beside it on a low-priority stream of the
+ * context's own, where it fills the end of the launch (A/B switch; the images are identical). */
+#define RRTX_FLAG_SKY_SAME_STREAM 8192
 
 /* The first bounce of every sample - camera ray, closest hit among the pixel's candidates, scatter - as a dense pre-pass of each launch that leaves one record per
  * sample, instead of inside the render loop (LIST passes).  Used by itself where it was measured to pay: use_bvh, scenes of spheres alone, launches of 32 M samples

@@ -10,7 +10,7 @@ Everything computes in librrtx.so (hand-written HIP for gfx950); nothing here fa
 Python/CPU arithmetic.
 """
 from ._lib import RrtxError  # noqa: F401
-from ._lib import FLAG_NO_FIRST_BOUNCE, FLAG_FIRST_BOUNCE_ALWAYS, FLAG_EXACT_ACCEL, FLAG_EXACT_SCAN, FLAG_NO_SKY_SPLIT, FLAG_NO_TAIL_GRID, FLAG_ONE_ITEM_PER_PIXEL, FLAG_SCAN_NO_MFMA  # noqa: F401  (rrtx_params.flags, include/rrtx.h)
+from ._lib import FLAG_NO_FIRST_BOUNCE, FLAG_SKY_SAME_STREAM, FLAG_FIRST_BOUNCE_ALWAYS, FLAG_EXACT_ACCEL, FLAG_EXACT_SCAN, FLAG_NO_SKY_SPLIT, FLAG_NO_TAIL_GRID, FLAG_ONE_ITEM_PER_PIXEL, FLAG_SCAN_NO_MFMA  # noqa: F401  (rrtx_params.flags, include/rrtx.h)
 from .render import Rrt, RrtGroup, Scene, device_count, query_device, quantise, write_png, write_ppm  # noqa: F401
 
-__all__ = ["Rrt", "RrtGroup", "Scene", "RrtxError", "FLAG_EXACT_SCAN", "FLAG_EXACT_ACCEL", "FLAG_NO_TAIL_GRID", "FLAG_SCAN_NO_MFMA", "FLAG_ONE_ITEM_PER_PIXEL", "FLAG_NO_SKY_SPLIT", "FLAG_NO_FIRST_BOUNCE", "FLAG_FIRST_BOUNCE_ALWAYS", "device_count", "query_device", "quantise", "write_png", "write_ppm"]
+__all__ = ["Rrt", "RrtGroup", "Scene", "RrtxError", "FLAG_EXACT_SCAN", "FLAG_EXACT_ACCEL", "FLAG_NO_TAIL_GRID", "FLAG_SCAN_NO_MFMA", "FLAG_ONE_ITEM_PER_PIXEL", "FLAG_NO_SKY_SPLIT", "FLAG_NO_FIRST_BOUNCE", "FLAG_SKY_SAME_STREAM", "FLAG_FIRST_BOUNCE_ALWAYS", "device_count", "query_device", "quantise", "write_png", "write_ppm"]

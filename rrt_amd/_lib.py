@@ -209,6 +209,7 @@ FLAG_ONE_ITEM_PER_PIXEL = 512
 FLAG_NO_SKY_SPLIT = 1024
 FLAG_NO_FIRST_BOUNCE = 2048
 FLAG_FIRST_BOUNCE_ALWAYS = 4096
+FLAG_SKY_SAME_STREAM = 8192
 
 
 class RrtxError(RuntimeError):

@@ -108,6 +108,10 @@ struct rrtx_ctx {
     std::vector<std::pair<void **, size_t>> caps; // capacities of the per-scene device buffers (see ensure_buffer)
     // timing
     hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
+    // the sky split's kernel runs BESIDE the render kernel, on a stream of its own of the lowest priority: the persistent render kernel fills the device, the
+    // sky kernel's blocks move in as its waves retire - into the end of the launch, where a handful of 50-bounce paths are all that is left to do
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ev_pending = 0;
     double kernel_ms_total = 0.0;
     long renders_total = 0;
@@ -454,6 +458,13 @@ int rrtx_create(const rrtx_params *params, rrtx_ctx **out)
     c->use_partial = c->chunks_per_pixel > 1 || tapered_pixels > 0;
 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     // (one allocation: the launch's control words - 256 bytes - and the statistics counters behind them are cleared by ONE fill per launch)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_queue, 512);
     if (e == hipSuccess) c->d_counters = (unsigned long long *)(c->d_queue + 64);
@@ -497,6 +508,7 @@ void rrtx_destroy(rrtx_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->ev_pending; ++i) (void)hipEventSynchronize(c->ev_stop[i]); // (renders enqueued on a caller's stream)
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     free_scene_buffers(c); // everything rrtx_set_scene allocated: tables (the matrix form's operands too), grid, lists, parked-item buffers
     void *bufs[] = {c->d_queue, c->d_partial, c->d_rows};
     for (void *b : bufs)
@@ -508,6 +520,9 @@ void rrtx_destroy(rrtx_ctx *c)
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
     }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -682,14 +697,38 @@ int rrtx_render_device(rrtx_ctx *c, void *d_rows, void *hip_stream)
         typedef decltype(fp) F;
         KernelParams<F> P = make_params<F>(c, out, c->accel);
         hipError_t e = hipSuccess;
-        if (c->have_split) { // the tasks of the sky-only pixels: a dense kernel of camera rays (rrtx_kernels.hip: the sky split)
-            const uint32_t first = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel;
-            e = launch_sky_tasks<F>(P, first, c->total_tasks - first, c->num_cus, st);
+        bool forked = false;
+        // (the first bounce first: the sky kernel is to run beside the persistent render kernel - beside another dense kernel it would only share the device with it)
+        if (c->have_first) e = launch_first_bounce<F>(P, P.total_tasks, c->num_cus, st); // (the queue's positions: every task, or those of the pixels the sky split left)
+        // the tasks of the sky-only pixels: a dense kernel of camera rays (rrtx_kernels.hip: the sky split).  Beside the render kernel: its stream waits for what
+        // precedes the render kernel on the caller's stream (this launch's fill of the control words), the caller's stream waits for it before the sums are formed;
+        // and it is enqueued after the render kernel.  (Measured, kernel trace: the device starts it 0.13 ms BEFORE the render kernel either way, and its 0.42 ms
+        // disappear in the render kernel's first half millisecond, where 390 000 lanes all fetch tables, pull tasks and form camera rays at once: C3 50.24 -> 49.77 ms,
+        // use_bvh 36.56 -> 35.88, C4 use_bvh 56.1 -> 55.6.)
+        if (e == hipSuccess && c->have_split && !(c->p.flags & RRTX_FLAG_SKY_SAME_STREAM)) {
+            e = hipEventRecord(c->ev_fork, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+            forked = e == hipSuccess;
         }
-        if (e == hipSuccess && c->have_first) e = launch_first_bounce<F>(P, P.total_tasks, c->num_cus, st); // (the queue's positions: every task, or those of the pixels the sky split left)
+        auto launch_sky = [&]() {
+            const uint32_t first = c->n_queue_pixels * (uint32_t)c->chunks_per_pixel;
+            hipError_t es = launch_sky_tasks<F>(P, first, c->total_tasks - first, c->num_cus, forked ? c->side_stream : st);
+            if (forked) {
+                const hipError_t e2 = hipEventRecord(c->ev_join, c->side_stream);
+                if (es == hipSuccess) es = e2;
+            }
+            return es;
+        };
+        const bool sky_first = !forked;
+        if (e == hipSuccess && c->have_split && sky_first) e = launch_sky();
         if (e == hipSuccess) e = launch_render<F>(P, c->use_filter, c->lds_mode, c->grid_blocks, st);
+        if (e == hipSuccess && c->have_split && !sky_first) e = launch_sky();
         if (e == hipSuccess && c->tail_capacity)
             e = (c->accel || c->tail_grid) ? launch_resume<F>(make_params<F>(c, out, true), c->use_filter, c->resume_blocks, st) : launch_tail<F>(P, c->use_filter, c->tail_blocks, st);
+        if (forked) { // (also after an error: whatever went to the side stream is waited for by the caller's stream, which the error path drains)
+            const hipError_t e2 = hipStreamWaitEvent(st, c->ev_join, 0);
+            if (e == hipSuccess) e = e2;
+        }
         if (e == hipSuccess && c->use_partial) e = launch_finalize<F>((const F *)c->d_partial, (F *)d_rows, shape, st);
         if (e == hipSuccess) e = hipEventRecord(c->ev_stop[slot], st);
         return e;
