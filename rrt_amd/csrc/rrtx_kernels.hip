@@ -484,6 +484,19 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     uint32_t out_index = 0; // RESUME: where the unit's result goes in tail_rad
     bool single = false;    // RESUME: the result is the sample itself (units k >= 1), not a running sum
     const uint32_t n_units_in = RESUME ? P.tail_count[2] : 0u;
+    // RESUME: the FIRST 64 units of every wave are dealt, not pulled.  The waves of a pass all start within microseconds of one another, atomics on one word are served
+    // one after the other (88 per microsecond: MI355X_MICROARCH.md), and what a launch parks rarely fills a tenth of the grid: the few waves with work queued behind
+    // thousands that only came to find the cursor past the end.  Dealt, no wave of an ordinary pass touches the cursor at all (it counts from `dealt` on): C3 shard of 8
+    // 7.25 -> 7.01 ms, C2 1.15 -> 1.13, fp64 mesh 6.72 -> 6.52.  (The same for the render kernel's first batch costs a full frame 1.5 % and buys C2 another 2 %: not
+    // done.  EXPERIMENTS.md, round 4.)
+    uint32_t dealt = 0;
+    if (RESUME) {
+        const uint32_t wave_id = blockIdx.x * (uint32_t)kWPB + (uint32_t)wave;
+        dealt = n_waves * 64u;
+        pool_next = wave_id * 64u < n_units_in ? wave_id * 64u : n_units_in;
+        pool_end = n_units_in - pool_next < 64u ? n_units_in : pool_next + 64u;
+        if (dealt >= n_units_in) queue_dry = queue_over = true; // (everything was dealt)
+    }
     uint32_t n_segments = 0, n_candidates = 0, n_scanned = 0;
     uint32_t n_walk_cells = 0, n_walk_pairs = 0; // dense variants: cells stepped through, (ray, entry) pairs tested
 #ifdef RRTX_RESUME_DIAG
@@ -565,7 +578,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 if (queue_dry) break;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(P.tail_count + 1, 64u);
-                base = __builtin_amdgcn_readfirstlane(base);
+                base = __builtin_amdgcn_readfirstlane(base) + dealt;
                 if (base >= n_units_in) {
                     queue_dry = queue_over = true;
                     break;
