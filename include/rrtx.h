@@ -130,7 +130,8 @@ typedef struct rrtx_params {
                                           kernel once the queue is dry and at most this many of
                                           its 64 lanes are alive; 0 = default (7)              */
     int32_t handoff_iters;             /* tuning: ... or this many iterations after the queue ran
-                                          dry, whichever comes first; 0 = default (12)          */
+                                          dry, whichever comes first; 0 = default (20; 4 for scenes
+                                          with triangles / moving spheres under use_bvh)        */
     int32_t list_passes;               /* tuning: camera-ray LIST passes allowed between two SCAN
                                           passes; 0 = default (3), -1 = none                    */
     int32_t taper_samples;             /* tuning: this many samples at the end of the work queue are

@@ -273,7 +273,7 @@ template <typename F> KernelParams<F> make_params(const rrtx_ctx *c, void *out, 
     P.counters = c->d_counters;
     P.collect_stats = c->p.collect_stats;
     P.handoff_lanes = c->tail_capacity ? c->handoff_lanes : 0;
-    P.handoff_iters = c->p.handoff_iters > 0 ? c->p.handoff_iters : kHandoffIters;
+    P.handoff_iters = c->p.handoff_iters > 0 ? c->p.handoff_iters : ((c->accel && (c->n_msph > 0 || c->n_tri > 0)) ? kHandoffItersDense : kHandoffIters); // (dense: the variants that pair (ray, entry) across the wave)
     P.tail_count = c->d_queue + 1;
     P.tail_items = (TailItem<F> *)c->d_tail_items;
     P.tail_rad = (F *)c->d_tail_rad;

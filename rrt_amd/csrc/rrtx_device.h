@@ -83,7 +83,11 @@ constexpr int kPlistCap = 15;    // sphere indices per pixel in the camera-ray c
 constexpr int kPlistStride = 16; // ... stored as uint16 [count | 0xFFFF, idx...]: 32 bytes per pixel
 constexpr int kListPasses = 3;   // LIST passes allowed between two SCAN passes (measured: 1 -> 80.9, 2 -> 79.8, 3 -> 79.0, 6 -> 78.7 ms)
 constexpr int kTailSplit = 8;    // a parked item is finished as up to this many independent units (3 bits in tail_units)
-constexpr int kHandoffIters = 12; // ... and after this many iterations past queue-dry regardless of the lane count (final.txt 1200x800, 8 / 12 / 16 / 24: spp 8 3.28 / 3.12 / 2.98 / 2.85 ms, an eighth of the spp 500 frame 11.42 / 11.30 / 11.32 / 11.38, the whole of it 77.5 / 77.6 / 77.7 / 78.0)
+// ... and after this many iterations past queue-dry regardless of the lane count.  Round 4, with the resume pass's units dealt (a pass costs 60 us less than it did): the
+// list scan and the variants for scenes of spheres alone 4 / 8 / 12 / 16 / 20 / 24: C2 1.115 / 1.067 / 1.035 / 0.989 / 0.975 / 0.982 ms, test3.txt spp 10 1.51 / 1.42 / 1.31 /
+// 1.28 / 1.26 / 1.28, an eighth of C3 6.83 / 6.80 / 6.78 / 6.76 / 6.79 / 6.75, the whole of it flat; the densely pairing variants (a mesh under use_bvh: an iteration of
+// theirs is 16 us, and the resume pass repacks what is left) 2 / 4 / 8 / 12 / 20: 5.16 / 5.15 / 5.30 / 5.47 / 5.73 ms, fp64 6.05 / 6.04 / 6.22 / 6.49 / 7.10.
+constexpr int kHandoffIters = 20, kHandoffItersDense = 4;
 
 template <typename F> struct alignas(4 * sizeof(F)) SphereHot {
     F cx, cy, cz, r2;
