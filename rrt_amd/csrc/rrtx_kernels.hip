@@ -394,8 +394,12 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SO ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SO ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : RRTX_MF_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, int SOV = 0> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SOV != 0 ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SOV != 0 ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : RRTX_MF_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
 {
+    // SOV: 0 = scenes of every kind; 1 = spheres alone (SO: the branches that tell the kinds apart are compiled out); 2 = spheres alone AND every fresh sample of the
+    // launch is a first-bounce record (KernelParams::first is set: first_bounce_kernel ran) - camera rays and LIST passes are compiled out of the loop as well
+    // (final.txt use_bvh 36.3 -> 35.6 ms, fp64 56.25 -> 55.6 against the same loop deciding at run time)
+    constexpr bool SO = SOV != 0, kFirstAlways = SOV == 2;
     constexpr int kBT = LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads, kWPB = kBT / 64; // threads, waves of a block of this variant
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -709,7 +713,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             int pi, pj, sf, se;
             const auto &C = *cold_params<F>();
             task_decode<F>(C, task, pi, pj, sf, se);
-            if (C.first == nullptr) {
+            const bool no_first = kFirstAlways ? false : C.first == nullptr;
+            if (no_first) {
                 need_ray = false;
                 camera_ray<F>(C, pi, pj, s_cur, rng, path);
                 // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
@@ -2070,17 +2075,19 @@ template <typename F> __global__ void __launch_bounds__(256) deinterleave_kernel
 // ---------------------------------------------------------------------------------------------
 // launch wrappers (called from rrtx_api.cpp)
 // ---------------------------------------------------------------------------------------------
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, bool SO = false> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, int SOV = 0> hipError_t launch_variant(const KernelParams<F> &P, int grid_blocks, size_t lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SO>), dim3(grid_blocks), dim3(LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), lds_bytes, stream, P);
+    hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SOV>), dim3(grid_blocks), dim3(LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
 }
 // the accelerated variants (render and resume passes): tables in LDS or in HBM, scenes of spheres alone or of every kind
 template <typename F, bool FILTER, bool RESUME> hipError_t launch_accel(const KernelParams<F> &P, int grid_blocks, size_t alds, hipStream_t stream)
 {
     const bool spheres_only = P.n_msph == 0 && P.n_tri == 0;
-    if (alds) return spheres_only ? launch_variant<F, FILTER, 0, false, 2, RESUME, true>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 2, RESUME, false>(P, grid_blocks, alds, stream);
-    return spheres_only ? launch_variant<F, FILTER, 0, false, 1, RESUME, true>(P, grid_blocks, 0, stream) : launch_variant<F, FILTER, 0, false, 1, RESUME, false>(P, grid_blocks, 0, stream);
+    if (!RESUME && spheres_only && P.first != nullptr) // (the render pass of a launch with a first-bounce pre-pass; its resume pass, a few thousand paths, decides at run time)
+        return alds ? launch_variant<F, FILTER, 0, false, 2, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 1, false, 2>(P, grid_blocks, 0, stream);
+    if (alds) return spheres_only ? launch_variant<F, FILTER, 0, false, 2, RESUME, 1>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 2, RESUME, 0>(P, grid_blocks, alds, stream);
+    return spheres_only ? launch_variant<F, FILTER, 0, false, 1, RESUME, 1>(P, grid_blocks, 0, stream) : launch_variant<F, FILTER, 0, false, 1, RESUME, 0>(P, grid_blocks, 0, stream);
 }
 // bytes of LDS the accelerated variant wants for its tables (0: they stay in HBM)
 template <typename F> size_t accel_lds_bytes(const KernelParams<F> &P)
