@@ -190,8 +190,8 @@ typedef struct rrtx_params {
 /* The first bounce of every sample - camera ray, closest hit among the pixel's candidates, scatter - as a dense pre-pass of each launch that leaves one record per
  * sample, instead of inside the render loop (LIST passes).  Used by itself where it was measured to pay: use_bvh, scenes of spheres alone, launches of 32 M samples
  * and more, and 8 values of the frame's precision per sample of device memory to spare (15 GB for 1200x800 spp 500 in fp32); skipped silently otherwise.
- * NO_FIRST_BOUNCE never uses it, FIRST_BOUNCE_ALWAYS uses it for every launch of a scene of spheres alone (with or without use_bvh) that has the memory: A/B
- * switches, the images are identical. */
+ * NO_FIRST_BOUNCE never uses it, FIRST_BOUNCE_ALWAYS uses it for every use_bvh launch of a scene of spheres alone that has the memory, whatever its size (the
+ * list scan never does: measured to gain nothing there, its kernels are compiled without the record path): A/B switches, the images are identical. */
 #define RRTX_FLAG_NO_FIRST_BOUNCE 2048
 #define RRTX_FLAG_FIRST_BOUNCE_ALWAYS 4096
 

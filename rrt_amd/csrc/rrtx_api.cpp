@@ -610,7 +610,7 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
         // 1200x800 spp 500, nothing at a shard of 8 of it (60 M samples), 1.16 -> 1.41 ms at spp 10; with the list scan nothing anywhere (its loop is bound by
         // the scan passes, which a lane without a camera ray does not shorten).  Otherwise, and for scenes with anything but spheres, the render loop forms its
         // camera rays itself (LIST passes), as up to round 3.
-        const bool first_pays = (c->p.flags & RRTX_FLAG_FIRST_BOUNCE_ALWAYS) || (c->accel && (size_t)c->total_tasks * (size_t)c->chunk >= kFirstBounceMinSamples);
+        const bool first_pays = c->accel && ((c->p.flags & RRTX_FLAG_FIRST_BOUNCE_ALWAYS) || (size_t)c->total_tasks * (size_t)c->chunk >= kFirstBounceMinSamples);
         if (first_pays && c->n_msph == 0 && c->n_tri == 0 && c->taper_pixel == n_px && c->p.max_depth > 0 && c->p.list_passes >= 0 && c->n_mat <= 65536 &&
             !(c->p.flags & (RRTX_FLAG_NO_FIRST_BOUNCE | RRTX_FLAG_VERIFY_LISTS))) {
             const size_t bytes = (((size_t)c->total_tasks + 63) / 64) * 64 * (size_t)c->chunk * 8 * c->fsize;

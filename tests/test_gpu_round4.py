@@ -124,6 +124,9 @@ def test_sky_split_and_first_bounce_leave_the_frame_alone(gpu, fp64):
             img, so = want[(depth, None if kw.get("sample_chunk") == -1 else 8)]
             assert np.array_equal(fb, img) and np.array_equal(fb2, img), (flags, kw, depth)
             assert st["segments"] == so["segments"] and st["convergence_faults"] == 0, (flags, kw, depth)
+            # (the passes asked for are the passes that ran: the pre-pass belongs to use_bvh launches - the list scan was measured to gain nothing from it)
+            assert st["first_bounce"] == int(bool(flags & gpu.FLAG_FIRST_BOUNCE_ALWAYS) and kw.get("use_bvh", False) and depth > 0), (flags, kw, depth)
+            assert (st["sky_pixels"] > 0) == (not (flags & gpu.FLAG_NO_SKY_SPLIT) and depth > 0), (flags, kw, depth)
     # a shard of the frame, and a frame whose every pixel has candidates (no sky-only pixel: the plain queue)
     for flags in (0, gpu.FLAG_FIRST_BOUNCE_ALWAYS):
         r = gpu.Rrt(w, h, spp, 50, fp64=fp64, use_bvh=True, flags=flags, shard_rank=1, shard_count=3, tile_rows=4)
