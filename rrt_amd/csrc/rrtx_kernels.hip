@@ -158,10 +158,10 @@ RRTX_DEV void load_unit(const KernelParams<F> &P, uint32_t u, uint32_t &task, in
 // A sample's radiance is known: rrt.cu:115, `pixel_color += ray_color(...)`, then the next sample or the end of the task.
 // per_sample launches (the reference's own summation order at the speed of small work items): nothing is added here - the sample's
 // radiance goes to its own slot, [pixel][sample][3], and finalize_kernel forms the pixel's running sum in sample order.
-template <typename F, bool RESUME> RRTX_DEV void finish_sample(const KernelParams<F> &P, const V3<F> &radiance, uint32_t task, int &s_cur, int s_end, bool single, uint32_t out_index, V3<F> &acc, bool &need_task, bool &need_ray)
+template <typename F, bool RESUME, bool PLAIN = false> RRTX_DEV void finish_sample(const KernelParams<F> &P, const V3<F> &radiance, uint32_t task, int &s_cur, int s_end, bool single, uint32_t out_index, V3<F> &acc, bool &need_task, bool &need_ray)
 {
     const auto &C = *cold_params<F>();
-    if (C.per_sample) {
+    if (!PLAIN && C.per_sample) {
         F *o = C.out + ((size_t)task_pixel<F>(C, task) * (size_t)C.spp + (size_t)s_cur) * 3;
         o[0] = radiance.x, o[1] = radiance.y, o[2] = radiance.z;
         s_cur += 1;
@@ -394,12 +394,15 @@ __device__ __forceinline__ void dense_candidates(const KernelParams<F> &P, const
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 constexpr uint32_t kCoopWait = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu; // walk_cell of a far ray before / after the wave's scan (cells use 30 bits)
-template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, int SOV = 0> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? (SOV != 0 ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : (SOV != 0 ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : RRTX_MF_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
+template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RESUME = false, int SOV = 0> __global__ void __launch_bounds__((LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), (ACCEL != 0 ? (sizeof(F) == 4 ? ((SOV & 3) != 0 ? RRTX_ACCEL_WAVES : RRTX_DENSE_WAVES) : ((SOV & 3) != 0 ? RRTX_ACCEL_WAVES_F64 : RRTX_DENSE_WAVES_F64)) : (LDSMODE == 3 ? (sizeof(F) == 4 ? 4 : RRTX_MF_WAVES_F64) : (sizeof(F) == 8 ? RRTX_LIST_WAVES_F64 : 1)))) render_kernel(const KernelParams<F> P)
 {
     // SOV: 0 = scenes of every kind; 1 = spheres alone (SO: the branches that tell the kinds apart are compiled out); 2 = spheres alone AND every fresh sample of the
     // launch is a first-bounce record (KernelParams::first is set: first_bounce_kernel ran) - camera rays and LIST passes are compiled out of the loop as well
     // (final.txt use_bvh 36.3 -> 35.6 ms, fp64 56.25 -> 55.6 against the same loop deciding at run time)
-    constexpr bool SO = SOV != 0, kFirstAlways = SOV == 2;
+    // (the matrix-core list scan is chosen for scenes of spheres alone only: rrtx_api.cpp.  C3 49.22 -> 48.66 ms, C4 65.3 -> 64.9, C2 1.125 -> 1.106)
+    // SOV & 4 (kPlain): the launch has no single-sample tasks at its end, a queue order (the sky split) and per-task sums - decided once per launch, not asked at
+    // every task and sample (C3 48.63 -> 48.04 ms, C4 64.8 -> 63.8, use_bvh 35.69 -> 35.59 / 55.2 -> 54.6).  Never in a resume pass.
+    constexpr bool SO = (SOV & 3) != 0 || LDSMODE == 3, kFirstAlways = (SOV & 3) == 2, kPlain = (SOV & 4) != 0 && !RESUME;
     constexpr int kBT = LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads, kWPB = kBT / 64; // threads, waves of a block of this variant
     // candidate slots per lane for the scan: the accelerated variants scan one segment in a hundred
     // thousand and rather keep the LDS for a sixth block per CU
@@ -628,9 +631,9 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     plist_count = 0xFFFFu; // a path in flight has no camera-ray list (a fresh camera ray fetches its own)
                 }
                 else {
-                    task = queue_task(*cold_params<F>(), pool_next + rank);
+                    task = queue_task<kPlain>(*cold_params<F>(), pool_next + rank);
                     int pi, pj;
-                    task_decode<F>(*cold_params<F>(), task, pi, pj, s_cur, s_end);
+                    task_decode<F, kPlain>(*cold_params<F>(), task, pi, pj, s_cur, s_end);
                     acc = mk<F>(0, 0, 0);
                     need_ray = true;
                 }
@@ -698,8 +701,8 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     const bool mine = pool_next + (uint32_t)lane < pool_end;
                     TailItem<F> fresh = {};
                     int pi, pj, sf = 0, se = 0;
-                    const uint32_t fresh_task = mine ? queue_task(*cold_params<F>(), pool_next + (uint32_t)lane) : 0u;
-                    if (mine) task_decode<F>(*cold_params<F>(), fresh_task, pi, pj, sf, se);
+                    const uint32_t fresh_task = mine ? queue_task<kPlain>(*cold_params<F>(), pool_next + (uint32_t)lane) : 0u;
+                    if (mine) task_decode<F, kPlain>(*cold_params<F>(), fresh_task, pi, pj, sf, se);
                     fresh.task = fresh_task, fresh.s_cur = sf, fresh.need_ray = 1u;
                     park(mine, fresh, se - sf < kTailSplit ? se - sf : kTailSplit);
                 }
@@ -712,14 +715,14 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // ---------------- camera ray: rrt.cu:112-114, camera.h:31-38 --------------------------
             int pi, pj, sf, se;
             const auto &C = *cold_params<F>();
-            task_decode<F>(C, task, pi, pj, sf, se);
+            task_decode<F, kPlain>(C, task, pi, pj, sf, se);
             // (the list-scan variants never meet a pre-pass - it was measured to gain them nothing - and are compiled without the record path: C3 49.66 -> 49.39 ms)
             const bool no_first = kFirstAlways ? false : (ACCEL == 0 ? true : C.first == nullptr);
             if (no_first) {
                 need_ray = false;
                 camera_ray<F>(C, pi, pj, s_cur, rng, path);
                 // this pixel's camera-ray candidate list (header: count, or 0xFFFF = "scan everything")
-                plist_count = C.plist ? (uint32_t)C.plist[(size_t)task_pixel<F>(C, task) * kPlistStride] : 0xFFFFu;
+                plist_count = C.plist ? (uint32_t)C.plist[(size_t)task_pixel<F, kPlain>(C, task) * kPlistStride] : 0xFFFFu;
             }
             else {
                 // The first bounce of every sample was done before this kernel started (first_bounce_kernel: one lane per task, all lanes at work on neighbouring
@@ -739,7 +742,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     if (kind == kFirstDone) {
                         need_ray = false;
                         n_segments += 1; // (counted where the record is consumed: a sample the tail kernel finishes is traced there from its camera ray, and counted there)
-                        finish_sample<F, RESUME>(P, mk<F>(p0.x, p0.y, p0.z), task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
+                        finish_sample<F, RESUME, kPlain>(P, mk<F>(p0.x, p0.y, p0.z), task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
                         continue;
                     }
                     need_ray = false;
@@ -1051,7 +1054,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                 static_assert(kPlistStride == 16 && kCap >= 8, "a pixel's list is 8 dwords");
                 const auto &C = *cold_params<F>();
                 typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-                const U4 *pl4 = (const U4 *)(C.plist + (size_t)task_pixel<F>(C, task) * kPlistStride);
+                const U4 *pl4 = (const U4 *)(C.plist + (size_t)task_pixel<F, kPlain>(C, task) * kPlistStride);
                 const U4 lo4 = pl4[0], hi4 = pl4[1];
                 my_cand[0 * 64] = lo4.x, my_cand[1 * 64] = lo4.y, my_cand[2 * 64] = lo4.z, my_cand[3 * 64] = lo4.w;
                 my_cand[4 * 64] = hi4.x, my_cand[5 * 64] = hi4.y, my_cand[6 * 64] = hi4.z, my_cand[7 * 64] = hi4.w;
@@ -1259,7 +1262,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             } // max_depth > 0
 
             RRTX_SEC(6); // sample / task bookkeeping, stores
-            if (done) finish_sample<F, RESUME>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
+            if (done) finish_sample<F, RESUME, kPlain>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
         }
         } // !kDensePairs
         else {
@@ -1296,7 +1299,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
                     const F o2 = path.o.x * path.o.x + path.o.y * path.o.y + path.o.z * path.o.z;
                     if (a >= Limits<F>::coop_tiny() && a <= Limits<F>::coop_big() && o2 <= Limits<F>::coop_big() && ffabs(path.tm) <= Limits<F>::coop_big()) {
                         is_list = true;
-                        R.beg0 = task_pixel<F>(C, task), R.cnt = plist_count;
+                        R.beg0 = task_pixel<F, kPlain>(C, task), R.cnt = plist_count;
                         if (!SO) R.beg1 = (uint32_t)msph_base, R.beg2 = (uint32_t)tri_base, R.cnt |= ((uint32_t)n_msph << 8) | ((uint32_t)n_tri << 16); // (<= 64 of them where lists exist)
                     }
                     else
@@ -1379,7 +1382,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             RRTX_SEC(5);
             if (resolved) done = shade<F, SO>(P, best, path, rng, radiance);
             RRTX_SEC(6); // sample / task bookkeeping, stores
-            if (done) finish_sample<F, RESUME>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
+            if (done) finish_sample<F, RESUME, kPlain>(P, radiance, task, s_cur, s_end, single, out_index, acc, need_task, need_ray);
         }
     }
 
@@ -2081,10 +2084,16 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
     hipLaunchKernelGGL((render_kernel<F, FILTER, LDSMODE, VERIFY, ACCEL, RESUME, SOV>), dim3(grid_blocks), dim3(LDSMODE == 3 ? mf_block_threads(sizeof(F)) : kBlockThreads), lds_bytes, stream, P);
     return hipGetLastError();
 }
+// kPlain's condition (render_kernel, SOV & 4)
+template <typename F> bool launch_is_plain(const KernelParams<F> &P) { return P.taper_task_base >= P.total_tasks && P.pixel_order != nullptr && !P.per_sample; }
 // the accelerated variants (render and resume passes): tables in LDS or in HBM, scenes of spheres alone or of every kind
 template <typename F, bool FILTER, bool RESUME> hipError_t launch_accel(const KernelParams<F> &P, int grid_blocks, size_t alds, hipStream_t stream)
 {
     const bool spheres_only = P.n_msph == 0 && P.n_tri == 0;
+    if (!RESUME && FILTER && spheres_only && launch_is_plain(P)) { // (what a frame of a scene of spheres alone is by default: variants that know instead of asking)
+        if (P.first != nullptr) return alds ? launch_variant<F, FILTER, 0, false, 2, false, 6>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 1, false, 6>(P, grid_blocks, 0, stream);
+        return alds ? launch_variant<F, FILTER, 0, false, 2, false, 5>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 1, false, 5>(P, grid_blocks, 0, stream);
+    }
     if (!RESUME && spheres_only && P.first != nullptr) // (the render pass of a launch with a first-bounce pre-pass; its resume pass, a few thousand paths, decides at run time)
         return alds ? launch_variant<F, FILTER, 0, false, 2, false, 2>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 1, false, 2>(P, grid_blocks, 0, stream);
     if (alds) return spheres_only ? launch_variant<F, FILTER, 0, false, 2, RESUME, 1>(P, grid_blocks, alds, stream) : launch_variant<F, FILTER, 0, false, 2, RESUME, 0>(P, grid_blocks, alds, stream);
@@ -2109,7 +2118,9 @@ template <typename F> hipError_t launch_render(const KernelParams<F> &P, bool fi
     switch (lds_mode) {
     case 1: return launch_variant<F, true, 1, false, 0>(P, grid_blocks, lds, stream);
     case 2: return launch_variant<F, true, 2, false, 0>(P, grid_blocks, lds, stream);
-    case 3: return launch_variant<F, true, 3, false, 0>(P, grid_blocks, (size_t)((P.n_sph_padded + 31) & ~31) * 64, stream); // the filter on the matrix cores: 64 bytes of f16 operands per sphere
+    case 3: // the filter on the matrix cores: 64 bytes of f16 operands per sphere
+        if (launch_is_plain(P)) return launch_variant<F, true, 3, false, 0, false, 4>(P, grid_blocks, (size_t)((P.n_sph_padded + 31) & ~31) * 64, stream);
+        return launch_variant<F, true, 3, false, 0>(P, grid_blocks, (size_t)((P.n_sph_padded + 31) & ~31) * 64, stream);
     default: return launch_variant<F, true, 0, false, 0>(P, grid_blocks, 0, stream);
     }
 }

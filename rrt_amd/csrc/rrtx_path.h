@@ -256,16 +256,19 @@ template <typename FD> RRTX_DEV uint32_t fdiv(uint32_t n, const FD &f) // n / f.
     return f.is_one ? n : q;
 }
 
-template <typename F, typename PP> RRTX_DEV uint32_t task_pixel(const PP &P, uint32_t task)
+// PLAIN (here and below): the launch is known to have no single-sample tasks at its end, a queue order (the sky split) and per-task sums - what a frame of a scene of
+// spheres alone is by default.  The render kernel has variants compiled for that (a launch decides it once, the loop asked at every task: rrtx_kernels.hip, SOV).
+template <typename F, bool PLAIN = false, typename PP> RRTX_DEV uint32_t task_pixel(const PP &P, uint32_t task)
 {
+    if (PLAIN) return fdiv(task, P.div_cpp);
     return task < P.taper_task_base ? fdiv(task, P.div_cpp) : P.taper_pixel + fdiv(task - P.taper_task_base, P.div_spp);
 }
 
 // task -> (pixel, first/last sample)
-template <typename F, typename PP> RRTX_DEV void task_decode(const PP &P, uint32_t task, int &px_i, int &px_j, int &s_first, int &s_end)
+template <typename F, bool PLAIN = false, typename PP> RRTX_DEV void task_decode(const PP &P, uint32_t task, int &px_i, int &px_j, int &s_first, int &s_end)
 {
     uint32_t q;
-    if (task < P.taper_task_base) {
+    if (PLAIN || task < P.taper_task_base) {
         q = fdiv(task, P.div_cpp);
         const uint32_t c = task - q * (uint32_t)P.chunks_per_pixel;
         s_first = (int)c * P.chunk;
@@ -286,9 +289,9 @@ template <typename F, typename PP> RRTX_DEV void task_decode(const PP &P, uint32
 
 // Position in the work queue -> task (KernelParams::pixel_order: the sky split).  The chunks of a pixel stay together and in order; everything else - the slot a task's
 // sum goes to, the pixel and samples it stands for - is told by the TASK, so the order is scheduling only: the image does not know it.
-template <typename PP> RRTX_DEV uint32_t queue_task(const PP &P, uint32_t position)
+template <bool PLAIN = false, typename PP> RRTX_DEV uint32_t queue_task(const PP &P, uint32_t position)
 {
-    if (P.pixel_order == nullptr) return position;
+    if (!PLAIN && P.pixel_order == nullptr) return position;
     const uint32_t slot = fdiv(position, P.div_cpp);
     return P.pixel_order[slot] * (uint32_t)P.chunks_per_pixel + (position - slot * (uint32_t)P.chunks_per_pixel);
 }
