@@ -69,14 +69,14 @@ MFMA_FLOP = 2 * 32 * 32 * 16  # per v_mfma_f32_32x32x16_f16
 MF_BLOCK = 32          # spheres per block of the filter's table (rrtx_pack.h: kMfBlock)
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9       # nominal; a PMC pass measures the real one (GRBM_GUI_ACTIVE / 8 XCDs / duration)
-# Names as rocprofv3 prints them, up to and including the RESUME = false argument - prefixes, so that template
-# parameters added behind it (SO: scenes of spheres alone) do not lose the match (tests/test_cabi.py checks both
-# against the library's symbols): the list-scan render kernel of final.txt and the accelerated one.
+# Names as rocprofv3 prints them, up to and including the RESUME = false argument - prefixes: behind it stands SOV, the variant a launch selects by what it knows
+# about its scene and itself (spheres alone, a first-bounce pre-pass, no single-sample tasks: rrtx_kernels.hip); ONE of them runs per launch
+# (tests/test_cabi.py checks the names against the library's symbols): the list-scan render kernel of final.txt and the accelerated one.
 LIST_KERNEL = "render_kernel<float, true, 3, false, 0, false"
 ACCEL_KERNEL = "render_kernel<float, true, 0, false, 2, false"
-# the mesh sub-result: tables in HBM (ACCEL = 1), the render pass and the resume pass (RESUME = true) that finishes what it parks
-MESH_RENDER_KERNEL = "render_kernel<float, true, 0, false, 1, false, false"
-MESH_RESUME_KERNEL = "render_kernel<float, true, 0, false, 1, true, false"
+# the mesh sub-result: tables in HBM (ACCEL = 1), scenes of every kind (SOV = 0), the render pass and the resume pass (RESUME = true) that finishes what it parks
+MESH_RENDER_KERNEL = "render_kernel<float, true, 0, false, 1, false, 0>"
+MESH_RESUME_KERNEL = "render_kernel<float, true, 0, false, 1, true, 0>"
 MESH = (48, 96, 600, 400, 16)  # UV sphere of 48 x 96 quads instanced three times = 27 072 triangles; frame and spp of tests/test_gpu_mesh.py and VERDICT r02
 
 
