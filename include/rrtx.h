@@ -188,7 +188,7 @@ typedef struct rrtx_params {
 #define RRTX_FLAG_SKY_SAME_STREAM 8192
 
 /* The first bounce of every sample - camera ray, closest hit among the pixel's candidates, scatter - as a dense pre-pass of each launch that leaves one record per
- * sample, instead of inside the render loop (LIST passes).  Used by itself where it was measured to pay: use_bvh, scenes of spheres alone, launches of 32 M samples
+ * sample, instead of inside the render loop (LIST passes).  Used by itself where it was measured to pay: use_bvh, scenes of spheres alone, launches of 16 M samples
  * and more, and 8 values of the frame's precision per sample of device memory to spare (15 GB for 1200x800 spp 500 in fp32); skipped silently otherwise.
  * NO_FIRST_BOUNCE never uses it, FIRST_BOUNCE_ALWAYS uses it for every use_bvh launch of a scene of spheres alone that has the memory, whatever its size (the
  * list scan never does: measured to gain nothing there, its kernels are compiled without the record path): A/B switches, the images are identical. */
@@ -227,7 +227,7 @@ typedef struct rrtx_stats {
     int32_t sky_pixels;      /* pixels of this shard whose work items a dense kernel of camera rays finished (their candidate list is empty: sky in
                                 every sample); 0 = no split (RRTX_FLAG_NO_SKY_SPLIT, scenes with anything but spheres, no such pixel)     */
     int32_t first_bounce;    /* 1: the first bounce of every queued sample was a dense pre-pass of the launch (RRTX_FLAG_NO_FIRST_BOUNCE /
-                                RRTX_FLAG_FIRST_BOUNCE_ALWAYS; by itself: use_bvh, spheres alone, 32 M samples and more, memory to spare)  */
+                                RRTX_FLAG_FIRST_BOUNCE_ALWAYS; by itself: use_bvh, spheres alone, 16 M samples and more, memory to spare)  */
 } rrtx_stats;
 
 typedef struct rrtx_devinfo { /* the fields main.cpp:14-30 prints for -q */

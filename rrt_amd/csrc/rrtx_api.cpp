@@ -42,7 +42,7 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int kEventRing = 64;
-constexpr size_t kFirstBounceMinSamples = (size_t)32 << 20; // see set_scene
+constexpr size_t kFirstBounceMinSamples = (size_t)16 << 20; // see set_scene
 
 } // namespace
 
@@ -606,10 +606,11 @@ static int set_scene_impl(rrtx_ctx *c, const rrtx_scene_desc *s)
                 c->n_queue_pixels = n_first, c->have_split = true;
         }
         // the first bounce of every queued sample as a dense pre-pass of each launch: 8 F per sample (15 GB for 1200x800 spp 500 in fp32) - where the device can
-        // spare that and where it pays.  Measured on one box (EXPERIMENTS.md, round 4): with the grid walk 37.3 -> 36.3 ms (fp32) and 60.3 -> 56.4 ms (fp64) at
-        // 1200x800 spp 500, nothing at a shard of 8 of it (60 M samples), 1.16 -> 1.41 ms at spp 10; with the list scan nothing anywhere (its loop is bound by
-        // the scan passes, which a lane without a camera ray does not shorten).  Otherwise, and for scenes with anything but spheres, the render loop forms its
-        // camera rays itself (LIST passes), as up to round 3.
+        // spare that and where it pays.  Measured on one box (EXPERIMENTS.md, round 4): with the grid walk 37.3 -> 33.7 ms (fp32) and 60.3 -> 52.6 ms (fp64) at
+        // 1200x800 spp 500; by launch size, final.txt with / without: 61 M samples 5.16 / 5.48 ms, 31 M 3.13 / 3.23, 15 M 2.04 / 2.06, 7.7 M 1.43 / 1.42, 3.8 M
+        // 1.12 / 1.02 (the same for an eighth of the frame at as many samples); with the list scan nothing anywhere (its loop is bound by the scan passes, which a
+        // lane without a camera ray does not shorten).  Otherwise, and for scenes with anything but spheres, the render loop forms its camera rays itself (LIST
+        // passes), as up to round 3.
         const bool first_pays = c->accel && ((c->p.flags & RRTX_FLAG_FIRST_BOUNCE_ALWAYS) || (size_t)c->total_tasks * (size_t)c->chunk >= kFirstBounceMinSamples);
         if (first_pays && c->n_msph == 0 && c->n_tri == 0 && c->taper_pixel == n_px && c->p.max_depth > 0 && c->p.list_passes >= 0 && c->n_mat <= 65536 &&
             !(c->p.flags & (RRTX_FLAG_NO_FIRST_BOUNCE | RRTX_FLAG_VERIFY_LISTS))) {
