@@ -359,3 +359,14 @@ def test_triangle_box_overlap_is_conservative(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "tri_box_check.cpp")], check=True)
     r = subprocess.run([exe, "300000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_first_bounce_records_have_slots_of_their_own(tmp_path):
+    """rrtx_device.h's first_slot() against the buffer rrtx_api.cpp allocates: every (task, sample, part) inside it, no two in one slot, a wave's 64 tasks side by side;
+    the code word's fields apart (tests/first_slot_check.cpp, built here with g++: the header the kernels compile)."""
+    import subprocess
+
+    exe = str(tmp_path / "first_slot_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "first_slot_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "48 layouts ok" in r.stderr, r.stderr
