@@ -810,7 +810,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             unsigned char *const area = (unsigned char *)&cand_lds[wave][0][0];
             U4 *const stage = (U4 *)area;
             uint32_t *const marks = (uint32_t *)area; // slot s of lane l at [s * 64 + l]: block << 16 | the signs of the lane's 16 results for it
-            FV4 *const rays = (FV4 *)(area + 2048);   // ray r at [2 r], [2 r + 1]
+            FV4 *const rays = (FV4 *)(area + 2048);   // ray r: {o, a} at [r], {d, -} at [64 + r] (two arrays: SQ_LDS_BANK_CONFLICT 8.5e8 -> 5.5e8 per C3 launch against one array of pairs, 47.85 -> 47.64 ms)
             const F a = vlen2<F>(path.d); // sphere.h:36
             best.t = Limits<F>::inf(), best.idx = -1;
             const FilterRay fr = make_filter_ray_mf(path, a);
@@ -864,7 +864,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // the rays' records for the exact tests, the owners' result slots
             {
                 const FV4 r0 = {path.o.x, path.o.y, path.o.z, a}, r1 = {path.d.x, path.d.y, path.d.z, (F)0};
-                rays[2 * lane] = r0, rays[2 * lane + 1] = r1;
+                rays[lane] = r0, rays[64 + lane] = r1; // (two arrays: a gather of 16 lanes meets 16 bank groups instead of 8)
                 mf_keys[wave][lane] = ~0ull;
                 if (sizeof(F) == 8) mf_ranks[wave][lane] = 0u;
             }
@@ -877,7 +877,7 @@ template <typename F, bool FILTER, int LDSMODE, bool VERIFY, int ACCEL, bool RES
             // 32 block + 8 (v / 4) + 4 (lane / 32) + v % 4) - the instruction's result v of that tile; set = negative.
             // One pair to the exact test, its hit to the ray's owner: LDS minimum over (t, index) - consider()'s rule, as in dense_candidates()
             auto test_pair = [&](bool live, uint32_t owner, int idx) {
-                const FV4 r0 = rays[2u * owner], r1 = rays[2u * owner + 1u];
+                const FV4 r0 = rays[owner], r1 = rays[64u + owner];
                 const SphereHot<F> g = P.sph_hot[live ? idx : 0];
                 const F ra = r0.w;
                 const F ocx = r0.x - g.cx, ocy = r0.y - g.cy, ocz = r0.z - g.cz;
